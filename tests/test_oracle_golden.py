@@ -1,0 +1,118 @@
+"""Pin the CPU oracle (oracle/hrnet_cpu.py) to fixtures produced by the reference's own
+module (tests/golden/make_golden.py). CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hipnet import synth
+from oracle import hrnet_cpu as O
+
+
+def _state(salt=0, overrides=None):
+    tmpl = O.state_template()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(tmpl, salt).items()}
+    for k, v in (overrides or {}).items():
+        sd[k] = torch.from_numpy(v)
+    return sd
+
+
+def _checksum(t):
+    a = t.detach().double().reshape(-1)
+    n = a.numel()
+    idx = (np.arange(16, dtype=np.int64) * 2654435761 % n)
+    return np.concatenate([[a.sum().item(), a.abs().sum().item()], a[idx].numpy()])
+
+
+def test_state_template_matches_reference_inventory():
+    tmpl = O.state_template()
+    assert len(tmpl) == 1839                       # 921 params + 918 BN buffers
+    n_params = sum(int(np.prod(s)) for k, s in tmpl.items()
+                   if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    assert n_params == 29547477
+
+
+def test_eval_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'w32_eval_b1.npz'))
+    stats = {k[5:]: g[k] for k in g.files if k.startswith('stat.')}
+    sd = _state(0, stats)
+    x = torch.from_numpy(synth.rhd_batch(1, seed=1234)['imgs'])
+    with torch.no_grad():
+        hm, inter, _ = O.hrnet_forward(sd, O.W32_EXTRA, x, training=False)
+    assert np.abs(hm.numpy() - g['heatmaps']).max() <= 1e-5 * max(1.0, np.abs(g['heatmaps']).max())
+    np.testing.assert_allclose(_checksum(inter), g['inter_feat_checksum'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(inter[0, :, 10, 7:23].numpy(), g['inter_feat_slice'], rtol=1e-4, atol=1e-5)
+
+
+def test_train_forward_backward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'w32_train_b4.npz'))
+    sd = _state(0)
+    keys = [str(k) for k in g['grad_keys']]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    b = synth.rhd_batch(4, seed=1234)
+    hm, inter, new_stats = O.hrnet_forward(sd, O.W32_EXTRA, torch.from_numpy(b['imgs']), training=True)
+    loss = O.heatmap_loss(hm, torch.from_numpy(b['heatmaps']))
+    loss.backward()
+    assert abs(loss.item() - float(g['heatmap_loss'])) <= 1e-5 * abs(float(g['heatmap_loss']))
+    scale = max(1.0, np.abs(g['heatmaps0']).max())
+    assert np.abs(hm[0].detach().numpy() - g['heatmaps0']).max() <= 2e-5 * scale
+    cs = np.array([[sd[k].grad.double().sum().item(), sd[k].grad.double().abs().sum().item()] for k in keys])
+    np.testing.assert_allclose(cs[:, 1], g['grad_checksums'][:, 1], rtol=2e-4)
+    for k in g.files:
+        if k.startswith('grad.'):
+            ref = g[k]
+            got = sd[k[5:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), k
+        if k.startswith('stat.'):
+            np.testing.assert_allclose(new_stats[k[5:]].numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def test_small_train_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'w32_small_train_b2.npz'))
+    sd = _state(3)
+    b = synth.rhd_batch(2, seed=99, img_h=64, img_w=64)
+    hm, inter, _ = O.hrnet_forward(sd, O.W32_EXTRA, torch.from_numpy(b['imgs']), training=True)
+    assert np.abs(hm.detach().numpy() - g['heatmaps']).max() <= 2e-5 * max(1.0, np.abs(g['heatmaps']).max())
+    assert np.abs(inter.detach().numpy() - g['inter_feat']).max() <= 2e-5 * max(1.0, np.abs(g['inter_feat']).max())
+
+
+def test_losses_and_decode_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'micro.npz'))
+    p, t = torch.from_numpy(g['hl_pred']), torch.from_numpy(g['hl_gt'])
+    assert abs(O.heatmap_loss(p, t, 'l2').item() - float(g['hl_l2'])) <= 1e-5 * float(g['hl_l2'])
+    assert abs(O.heatmap_loss(p, t, 'l1').item() - float(g['hl_l1'])) <= 1e-5 * float(g['hl_l1'])
+    pp, pg, vis = (torch.from_numpy(g[k]) for k in ('jm_pred', 'jm_gt', 'jm_vis'))
+    assert abs(O.joints_mse_loss(pp, pg, vis).item() - float(g['jm_vis_loss'])) <= 1e-5 * float(g['jm_vis_loss'])
+    assert abs(O.joints_mse_loss(pp, pg).item() - float(g['jm_novis_loss'])) <= 1e-5 * float(g['jm_novis_loss'])
+    assert O.joints_mse_loss(pp, pg, torch.zeros(5, 21)).item() == float(g['jm_allinvis_loss']) == 0.0
+    pred = O.get_final_preds(torch.from_numpy(g['am_hm']), use_softmax=False)
+    assert np.array_equal(pred.numpy(), g['am_pred'])
+
+
+def test_argmax_decode_uses_height_as_row_stride_like_reference():
+    # heatmap_decoding.py:103-106 uses shape[2] (H) for both % and //, also on non-square maps
+    hm = torch.zeros(1, 1, 4, 6)
+    hm[0, 0, 2, 5] = 1.0                      # flat index 17
+    pred = O.get_final_preds(hm, use_softmax=False)
+    assert pred[0, 0].tolist() == [17 % 4, 17 // 4]
+
+
+def test_expectation_decode_definition():
+    hm = torch.zeros(1, 2, 8, 8)
+    hm[0, 0, 3, 5] = 1.0
+    hm[0, 1, 1, 2] = 0.5
+    hm[0, 1, 7, 6] = 0.5
+    pred = O.get_final_preds(hm, use_softmax=True)
+    assert torch.allclose(pred[0, 0], torch.tensor([5.0, 3.0]))
+    assert torch.allclose(pred[0, 1], torch.tensor([4.0, 4.0]))
+
+
+def test_get_max_preds_mask():
+    hm = np.zeros((1, 2, 4, 5), dtype=np.float32)
+    hm[0, 0, 3, 1] = 2.0
+    hm[0, 1] = -1.0
+    preds, maxvals = O.get_max_preds(hm)
+    assert preds[0, 0].tolist() == [1.0, 3.0] and preds[0, 1].tolist() == [0.0, 0.0]
+    assert maxvals[0, 0, 0] == 2.0 and maxvals[0, 1, 0] == -1.0
