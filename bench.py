@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""bench.py - images/sec of the pose_hrnet_w32 256x256 training step (forward + heat-map loss +
+backward + Adam) on N MI355X, batch 64 per GPU, bf16 MFMA with f32 accumulation/statistics.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0 (contract in the task statement). A "step" = one pass of the hot path over
+one synthetic RHD-shaped batch already resident in HBM: model forward, HeatmapLoss, backward,
+gradient all-reduce (N > 1, RCCL, overlapped with backward), fused Adam update.
+
+roofline      per-kernel HIP-event timing of one instrumented step (after the timed region); the
+              dominant MFMA kernel instantiation's algorithmic FLOP/launch over its mean launch time,
+              against the dense MFMA peak of the dtype (MI355X_MICROARCH.md: bf16 2.5 PF, f32 157.3 TF).
+cpu_baseline  the CPU oracle (oracle/hrnet_cpu.py, torch fp32 functional restatement of the
+              reference path, pinned to reference-generated fixtures) timed on this box's host cores
+              on a bounded sample (B=4 steps, about 10-30 s), rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, 'hrnet-hand-pose-estimation_amd')
+for p in (REPO, os.path.join(PKG, 'lib')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GFLOP_PER_IMG = {'w32': 67.70}      # fwd+bwd conv FLOPs / image, BASELINE.md section 2
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
+
+
+def build_model(dtype, yaml_name):
+    from config import get_cfg_defaults
+    from hipnet import synth
+    from models import pose_hrnet
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', yaml_name))
+    cfg.MODEL.COMPUTE_DTYPE = dtype
+    model = pose_hrnet.get_pose_net(cfg, is_train=False)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(model.state_dict(), 0).items()}
+    model.load_state_dict(sd)
+    return model, cfg, sd
+
+
+def conv_flops_table(plan):
+    """algorithmic FLOPs of every MFMA op of the recorded programs + its kernel instantiation name"""
+    from hipnet import _capi as C
+    buf = ctypes.create_string_buffer(160)
+
+    def flops(op, wgrad):
+        i = op.i
+        if wgrad:
+            n, ho, wo, cout, cin, ks = i[1], i[5], i[6], i[7], i[4], i[8]
+        else:
+            n, ho, wo, cout, cin, ks = i[1], i[5], i[6], i[7], i[4], i[8]
+            if i[10]:                      # zero-stuffed dgrad of a stride-2 conv: only 1/4 of the taps
+                return 2.0 * n * i[2] * i[3] * cout * cin * ks * ks   # are algorithmic: count the forward's
+        return 2.0 * n * ho * wo * cout * cin * ks * ks
+
+    out = {}
+    for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
+        for idx, op in enumerate(prog.ops):
+            if op.kind == C.OP_CONV:
+                C.call('hrnet_conv_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[10],
+                       buf, 160)
+                out[(pname, idx)] = (buf.value.decode(), flops(op, False))
+            elif op.kind == C.OP_WGRAD:
+                C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], buf, 160)
+                out[(pname, idx)] = (buf.value.decode(), flops(op, True))
+    return out
+
+
+def instrumented_step(model, x, gt, criterion):
+    """run one step op by op with HIP events on the launch stream; returns {kernel: [n, ms, flops]}"""
+    from hipnet import _capi as C
+    net = model.hip()
+    model.train()
+    with torch.no_grad():
+        net.pack_weights(for_backward=True)
+    plan = net.plan(x.shape[0], x.shape[2], x.shape[3], True, True)
+    table = conv_flops_table(plan)
+    # run both recorded programs op by op on the current stream (same buffers as the timed steps)
+    hm, inter = plan.run_forward(x)
+    g_hm = torch.empty_like(hm)
+    g_hm.copy_(hm - gt).mul_(2.0 / (hm.shape[0] * hm.shape[1]))
+    stats = {}
+    kinds = {}
+    net.prepare_grads()
+    plan.bwd.set_ptr(plan.gout_op, 0, g_hm.data_ptr())
+    for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
+        evs = []
+        for idx in range(len(prog)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            prog.run(idx, idx + 1)
+            e1.record()
+            evs.append((idx, e0, e1))
+        torch.cuda.synchronize()
+        for idx, e0, e1 in evs:
+            ms = e0.elapsed_time(e1)
+            key = (pname, idx)
+            if key in table:
+                name, fl = table[key]
+                s = stats.setdefault(name, [0, 0.0, 0.0])
+                s[0] += 1; s[1] += ms; s[2] += fl
+            k = kinds.setdefault(int(prog.ops[idx].kind), [0, 0.0])
+            k[0] += 1; k[1] += ms
+    net.mark_weights_dirty()
+    return stats, kinds
+
+
+def cpu_baseline(sd, extra, budget_s=20.0):
+    from hipnet import synth
+    from oracle import hrnet_cpu as O
+    # the box's CPU share, not the host's core count (a one-GPU box gets 16 cores)
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get('HRNET_CPU_THREADS', '16')))
+    torch.set_num_threads(cores)
+    b = synth.rhd_batch(4, seed=1234)
+    x, gt = torch.from_numpy(b['imgs']), torch.from_numpy(b['heatmaps'])
+    state = {k: v.clone() for k, v in sd.items()}
+    params = [v.requires_grad_(True) for k, v in state.items()
+              if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad()
+        hm, _, stats = O.hrnet_forward(state, extra, x, training=True)
+        loss = O.heatmap_loss(hm, gt)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            for k, v in stats.items():
+                state[k].copy_(v)
+    step()                                    # warm-up (allocations, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 >= budget_s or n >= 12:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': round(4 * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '{} optimiser steps of batch 4 (256x256, fp32, fwd+HeatmapLoss+bwd+Adam, anomaly mode off) '
+                      'after 1 warm-up, {:.1f} s'.format(n, dt)}
+
+
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from core.loss import HeatmapLoss
+    from hipnet import synth
+    from hipnet.optim import FlatAdam, GradSync
+    from oracle import hrnet_cpu as O    # cpu_baseline leg only
+
+    model, cfg, sd = build_model(args.dtype, 'RHD_HRNet_w32_max_hmloss_v1.yaml')
+    model = model.to(dev).train()
+    b = synth.rhd_batch(args.batch, seed=1234 + rank)
+    x = torch.from_numpy(b['imgs']).to(dev)
+    gt = torch.from_numpy(b['heatmaps']).to(dev)
+    criterion = HeatmapLoss()
+    opt = FlatAdam(model, lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
+    sync = None
+    if world > 1:
+        sync = GradSync(model)
+        opt.grad_scale = 1.0 / world
+
+    def step():
+        opt.zero_grad()
+        hm, _ = model(x)
+        loss = criterion(hm, gt)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        log('warm-up done, timing {} steps'.format(args.steps))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    roof = None
+    extra_out = {}
+    if rank == 0:
+        log('timed region {:.3f} s; instrumented per-kernel pass'.format(dt))
+    if rank == 0 and not args.no_roofline:
+        stats, kinds = instrumented_step(model, x, gt, criterion)
+        peak = PEAK_TFLOPS[args.dtype]
+        dom = max(stats.items(), key=lambda kv: kv[1][1])
+        name, (n, ms, fl) = dom
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 5), 'traffic': None, 'kernel': name, 'launches_per_step': n,
+                'avg_launch_us': round(ms / n * 1e3, 2)}
+        mfma_ms = sum(v[1] for v in stats.values())
+        mfma_fl = sum(v[2] for v in stats.values())
+        extra_out['mfma_kernels'] = {
+            'ms_per_step': round(mfma_ms, 3), 'tflops': round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2),
+            'frac_of_peak': round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / peak, 5),
+            'algorithmic_gflop_per_img': round(mfma_fl / args.batch / 1e9, 2)}
+        extra_out['kernel_ms'] = {k: [v[0], round(v[1], 3)] for k, v in
+                                  sorted(stats.items(), key=lambda kv: -kv[1][1])}
+        extra_out['op_kind_ms'] = {str(k): [v[0], round(v[1], 3)] for k, v in sorted(kinds.items())}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('cpu baseline (oracle on host cores)')
+        cpu = cpu_baseline(sd, O.W32_EXTRA)
+
+    if rank == 0:
+        imgs = world * args.batch * args.steps
+        value = imgs / dt
+        out = {
+            'metric': 'images/sec fwd+bwd pose_hrnet_w32 256x256 bs=64/GPU',
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'pose_hrnet_w32 256x256 {} fwd+HeatmapLoss+bwd+Adam training step, batch {}/GPU, '
+                                   'synthetic RHD-shaped crops, random-init weights'.format(args.dtype, args.batch),
+                       'global_batch': world * args.batch, 'parallelism': 'dp{}'.format(world)},
+            'step_mfma_frac': round(value * GFLOP_PER_IMG['w32'] / 1e3 / (world * PEAK_TFLOPS[args.dtype]), 5),
+            'final_loss': final_loss,
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        out.update(extra_out)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

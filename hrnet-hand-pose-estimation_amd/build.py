@@ -1,0 +1,63 @@
+"""Build libhrnet_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the tree)."""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(CSRC, 'libhrnet_hip.so')
+SOURCES = ['api.hip', 'conv.hip', 'wgrad.hip', 'eltwise.hip', 'loss.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(REPO, 'include', 'hrnet_hip.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
+         '-I', os.path.join(REPO, 'include'), '-I', CSRC, '-Wno-unused-result']
+
+
+def _stamp(src):
+    h = hashlib.sha1()
+    for p in [src] + HEADERS:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(name):
+    src = os.path.join(CSRC, name)
+    obj = os.path.join(OBJ, name.replace('.hip', '.o'))
+    stamp_file = obj + '.stamp'
+    stamp = _stamp(src)
+    if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for {}:\n{}\n{}'.format(name, r.stdout, r.stderr))
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
+    return obj, True
+
+
+def build(verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    rebuilt = any(c for _, c in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n{}\n{}'.format(r.stdout, r.stderr))
+    if verbose:
+        print('built' if rebuilt else 'up to date', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build()
+    sys.exit(0)

@@ -1,0 +1,191 @@
+// Shared device helpers for the gfx950 (CDNA4) HRNet kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hrnet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 V16;  // one 16-byte vector: 8 bf16 or 4 f32
+
+#define LDS_AS __attribute__((address_space(3)))
+
+// Per-dtype constants. VEC = elements per 16-byte vector. KSTEP = K extent of one
+// "fragment step": lane (i = l&15, g = l>>4) owns k = k0 + g*VEC + j, j < VEC, so one
+// 16-byte LDS read feeds one bf16 16x16x32 MFMA, or four f32 16x16x4 MFMAs.
+template <typename T>
+struct TT;
+template <>
+struct TT<float> {
+  static constexpr int VEC = 4;
+  static constexpr int KSTEP = 16;
+  static constexpr int ID = HR_F32;
+};
+template <>
+struct TT<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int KSTEP = 32;
+  static constexpr int ID = HR_BF16;
+};
+
+__device__ __forceinline__ V16 v16_zero() { return V16{0u, 0u, 0u, 0u}; }
+
+template <typename T>
+__device__ __forceinline__ void v16_unpack(const V16& v, float* f);
+template <>
+__device__ __forceinline__ void v16_unpack<float>(const V16& v, float* f) {
+  const f32x4 t = __builtin_bit_cast(f32x4, v);
+  f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void v16_unpack<bf16_t>(const V16& v, float* f) {
+  const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+  f[0] = __builtin_bit_cast(float, w0 << 16); f[1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, w1 << 16); f[3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
+  f[4] = __builtin_bit_cast(float, w2 << 16); f[5] = __builtin_bit_cast(float, w2 & 0xffff0000u);
+  f[6] = __builtin_bit_cast(float, w3 << 16); f[7] = __builtin_bit_cast(float, w3 & 0xffff0000u);
+}
+
+template <typename T>
+__device__ __forceinline__ V16 v16_pack(const float* f);
+template <>
+__device__ __forceinline__ V16 v16_pack<float>(const float* f) {
+  return __builtin_bit_cast(V16, f32x4{f[0], f[1], f[2], f[3]});
+}
+template <>
+__device__ __forceinline__ V16 v16_pack<bf16_t>(const float* f) {
+  // plain casts lower to v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+  const bf16x8 b = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3],
+                    (bf16_t)f[4], (bf16_t)f[5], (bf16_t)f[6], (bf16_t)f[7]};
+  return __builtin_bit_cast(V16, b);
+}
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float x) {
+  return (T)x;
+}
+
+// acc(16 couts x 16 pixels) += A(16 x KSTEP) * B(KSTEP x 16); a/b are the lane's 16-byte
+// fragments. D layout (all dtypes): col = lane&15, row = 4*(lane>>4) + reg.
+template <typename T>
+__device__ __forceinline__ f32x4 mma16(const V16& a, const V16& b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mma16<bf16_t>(const V16& a, const V16& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mma16<float>(const V16& a, const V16& b, f32x4 c) {
+  const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {
+  // sum over the 16 lanes that share (lane >> 4)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  v = wave_sum16(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Stage the input halo tile [HALO_H][HALO_W][KC channels from c0] of image n into LDS (pixel
+// stride PIXB bytes). The producer's BatchNorm affine (+ReLU) is applied on the way; padding
+// and the zero-stuffed grid of a stride-2 input gradient (upz) are zero AFTER the transform.
+template <typename T, int KC, int HALO_H, int HALO_W, int PIXB>
+__device__ __forceinline__ void stage_halo(char* xl, const char* x, int n, int H, int W, int Cin,
+                                           int Hz, int Wz, int iy0, int ix0, int c0,
+                                           const float* in_scale, const float* in_shift,
+                                           int in_relu, int upz, int tid) {
+  constexpr int VEC = TT<T>::VEC;
+  constexpr int VPP = KC / VEC;  // 16-byte vectors per pixel
+  static_assert(256 % VPP == 0, "each thread keeps one channel vector");
+  const int v = tid % VPP;
+  const int c = c0 + v * VEC;
+  const bool cvalid = c < Cin;
+  const bool has_affine = in_scale != nullptr;
+  float sc[VEC], sh[VEC];
+  if (has_affine && cvalid) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sc[j] = in_scale[c + j];
+      sh[j] = in_shift[c + j];
+    }
+  }
+  for (int idx = tid; idx < HALO_H * HALO_W * VPP; idx += 256) {
+    const int pix = idx / VPP;
+    const int hy = pix / HALO_W, hx = pix % HALO_W;
+    const int gy = iy0 + hy, gx = ix0 + hx;
+    bool ok = cvalid && gy >= 0 && gy < Hz && gx >= 0 && gx < Wz;
+    int sy = gy, sx = gx;
+    if (upz) {
+      ok = ok && !((gy | gx) & 1);
+      sy = gy >> 1;
+      sx = gx >> 1;
+      ok = ok && sy < H && sx < W;
+    }
+    V16 val = v16_zero();
+    if (ok) {
+      val = *(const V16*)(x + ((size_t)((n * H + sy) * W + sx) * Cin + c) * sizeof(T));
+      if (has_affine || in_relu) {
+        float f[VEC];
+        v16_unpack<T>(val, f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
+          if (in_relu) f[j] = fmaxf(f[j], 0.f);
+        }
+        val = v16_pack<T>(f);
+      }
+    }
+    *(V16*)(xl + pix * PIXB + v * 16) = val;
+  }
+}
+
+// host-side error plumbing (api.hip)
+void hr_set_error(const char* fmt, ...);
+int hr_check_launch(const char* what);
+
+#define HR_REQUIRE(cond, ...)  \
+  do {                         \
+    if (!(cond)) {             \
+      hr_set_error(__VA_ARGS__); \
+      return HR_E_BADARG;      \
+    }                          \
+  } while (0)
+
+// internal launchers (one per op kind), shared by the C entry points and the program runner
+int hr_launch_conv(const HrOp& op, hipStream_t s);
+int hr_launch_wgrad(const HrOp& op, hipStream_t s);
+int hr_launch_wgrad_reduce(const HrOp& op, hipStream_t s);
+int hr_launch_bn_finalize(const HrOp& op, hipStream_t s);
+int hr_launch_sum_terms(const HrOp& op, hipStream_t s);
+int hr_launch_grad_term(const HrOp& op, hipStream_t s);
+int hr_launch_bn_bwd_reduce(const HrOp& op, hipStream_t s);
+int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s);
+int hr_launch_bilinear_cat(const HrOp& op, hipStream_t s);
+int hr_launch_bilinear_cat_bwd(const HrOp& op, hipStream_t s);
+int hr_launch_im2col_stem(const HrOp& op, hipStream_t s);
+int hr_launch_nhwc_to_nchw(const HrOp& op, hipStream_t s);
+int hr_launch_nchw_to_nhwc(const HrOp& op, hipStream_t s);
+int hr_launch_pack_weights(const HrOp& op, hipStream_t s);
+int hr_launch_bias_grad(const HrOp& op, hipStream_t s);
+int hr_launch_fill(const HrOp& op, hipStream_t s);

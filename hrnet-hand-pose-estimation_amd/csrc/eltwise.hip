@@ -1,0 +1,822 @@
+// HBM-bound companions of the conv kernels: BatchNorm finalisation, fused multi-term sums
+// (residual adds, fuse-layer sums with nearest upsampling), their backward, the bilinear
+// head concat, layout conversions and weight packing. All are 16-byte-per-lane streaming
+// kernels; reductions are two-stage and deterministic (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(long long n) {
+  long long g = (n + EW_BLOCK - 1) / EW_BLOCK;
+  if (g > 256LL * 16) g = 256LL * 16;  // cap + grid-stride
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm finalize: stats[tiles][2][C] -> scale/shift (+ running stats update)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* stats, int tiles, int C, float count, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, long long* nbt, float momentum, float eps, int training,
+    float* scale, float* shift, float* save_mean, float* save_invstd) {
+  // block = 32 channels x 8 tile lanes
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (training && c < C) {
+    for (int t = tl; t < tiles; t += 8) {
+      s1 += (double)stats[((size_t)t * 2 + 0) * C + c];
+      s2 += (double)stats[((size_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[0][tl][cl] = s1;
+  red[1][tl][cl] = s2;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    float mean, var;
+    if (training) {
+      for (int k = 1; k < 8; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+      }
+      const double m = s1 / (double)count;
+      double v = s2 / (double)count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m;
+      var = (float)v;
+      if (running_mean) {
+        const float unbiased = count > 1.f ? (float)(v * (double)count / ((double)count - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = invstd;
+  }
+  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// sum_terms: out = relu_out( sum_t relu_t( src_t[up 2^sh_t] * scale_t + shift_t ) )
+// ---------------------------------------------------------------------------------------
+struct SumArgs {
+  char* out;
+  const char* src[4];
+  const float* scale[4];
+  const float* shift[4];
+  int sh[4];
+  int relu[4];
+  int N, Ho, Wo, C, nterms, relu_out;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.Ho * a.Wo * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    long long pix = idx / cv;
+    const int ox = (int)(pix % a.Wo);
+    pix /= a.Wo;
+    const int oy = (int)(pix % a.Ho);
+    const int n = (int)(pix / a.Ho);
+    const int c = v * VEC;
+    float accv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) accv[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < a.nterms) {
+        const int sh = a.sh[t];
+        const int hs = a.Ho >> sh, ws = a.Wo >> sh;
+        const size_t off = ((size_t)((n * hs + (oy >> sh)) * ws + (ox >> sh)) * a.C + c) * sizeof(T);
+        float f[VEC];
+        v16_unpack<T>(*(const V16*)(a.src[t] + off), f);
+        if (a.scale[t]) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], a.scale[t][c + j], a.shift[t][c + j]);
+        }
+        if (a.relu[t]) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) accv[j] += f[j];
+      }
+    }
+    if (a.relu_out) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) accv[j] = fmaxf(accv[j], 0.f);
+    }
+    *(V16*)(a.out + (size_t)idx * 16) = v16_pack<T>(accv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// grad_term / bn_bwd_reduce share the dz computation:
+//   dz[q,c] = sum_{p in block(q)} g[p,c] * [mask_out[p,c] > 0] * [scale*y+shift > 0 if inner_relu]
+// ---------------------------------------------------------------------------------------
+struct GradArgs {
+  char* dst;
+  const char* g;
+  const char* mask;
+  const char* y;
+  const float* scale;
+  const float* shift;
+  const float* coef;
+  float* partials;
+  int N, H, W, C, sh, inner_relu, accumulate;
+};
+
+template <typename T>
+__device__ __forceinline__ void compute_dz(const GradArgs& a, int n, int qy, int qx, int c,
+                                           float* dz, float* yv, bool need_y) {
+  constexpr int VEC = TT<T>::VEC;
+  const int f = 1 << a.sh;
+  const int Hg = a.H << a.sh, Wg = a.W << a.sh;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) dz[j] = 0.f;
+  for (int dy = 0; dy < f; ++dy)
+    for (int dx = 0; dx < f; ++dx) {
+      const size_t off =
+          ((size_t)((n * Hg + (qy << a.sh) + dy) * Wg + (qx << a.sh) + dx) * a.C + c) * sizeof(T);
+      float gv[VEC];
+      v16_unpack<T>(*(const V16*)(a.g + off), gv);
+      if (a.mask) {
+        float mv[VEC];
+        v16_unpack<T>(*(const V16*)(a.mask + off), mv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gv[j] = mv[j] > 0.f ? gv[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dz[j] += gv[j];
+    }
+  if (need_y || a.inner_relu) {
+    const size_t yoff = ((size_t)((n * a.H + qy) * a.W + qx) * a.C + c) * sizeof(T);
+    v16_unpack<T>(*(const V16*)(a.y + yoff), yv);
+    if (a.inner_relu) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float z = a.scale ? fmaf(yv[j], a.scale[c + j], a.shift[c + j]) : yv[j];
+        dz[j] = z > 0.f ? dz[j] : 0.f;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grad_term_kernel(GradArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.H * a.W * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    long long pix = idx / cv;
+    const int qx = (int)(pix % a.W);
+    pix /= a.W;
+    const int qy = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    const int c = v * VEC;
+    float dz[VEC], yv[VEC];
+    compute_dz<T>(a, n, qy, qx, c, dz, yv, a.coef != nullptr);
+    float o[VEC];
+    if (a.coef) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        o[j] = fmaf(a.coef[c + j], dz[j], fmaf(a.coef[a.C + c + j], yv[j], a.coef[2 * a.C + c + j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = dz[j];
+    }
+    char* d = a.dst + (size_t)idx * 16;
+    if (a.accumulate) {
+      float old[VEC];
+      v16_unpack<T>(*(const V16*)d, old);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += old[j];
+    }
+    *(V16*)d = v16_pack<T>(o);
+  }
+}
+
+// partials[block][2][C]; block = rows x cv threads, each thread owns one channel vector
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  __shared__ float red[256 * 2 * VEC];
+  const int cv = a.C / VEC;
+  const int rows = 256 / cv;
+  const int v = threadIdx.x % cv, row = threadIdx.x / cv;
+  const int c = v * VEC;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+  const long long npix = (long long)a.N * a.H * a.W;
+  if (row < rows) {
+    for (long long pix = (long long)blockIdx.x * rows + row; pix < npix; pix += (long long)gridDim.x * rows) {
+      const int qx = (int)(pix % a.W);
+      const long long r = pix / a.W;
+      const int qy = (int)(r % a.H);
+      const int n = (int)(r / a.H);
+      float dz[VEC], yv[VEC];
+      compute_dz<T>(a, n, qy, qx, c, dz, yv, true);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += dz[j];
+        s2[j] = fmaf(dz[j], yv[j], s2[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[(threadIdx.x * 2 + 0) * VEC + j] = s1[j];
+    red[(threadIdx.x * 2 + 1) * VEC + j] = s2[j];
+  }
+  __syncthreads();
+  // thread t < 2*C sums over rows for (which, channel)
+  for (int o = threadIdx.x; o < 2 * a.C; o += 256) {
+    const int which = o / a.C, ch = o % a.C;
+    const int vv = ch / VEC, jj = ch % VEC;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[((r * cv + vv) * 2 + which) * VEC + jj];
+    a.partials[((size_t)blockIdx.x * 2 + which) * a.C + ch] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* partials, int blocks, int C, float count, const float* gamma, const float* save_mean,
+    const float* save_invstd, float* dgamma, float* dbeta, float* coef, int accumulate) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int t = tl; t < blocks; t += 8) {
+      s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
+      s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+    }
+  red[0][tl][cl] = s1;
+  red[1][tl][cl] = s2;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int k = 1; k < 8; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
+    const double mu = save_mean[c], r = save_invstd[c], g = gamma[c];
+    const double dg = r * (s2 - mu * s1);  // sum dz * xhat
+    const double db = s1;
+    if (accumulate) {
+      dgamma[c] += (float)dg;
+      dbeta[c] += (float)db;
+    } else {
+      dgamma[c] = (float)dg;
+      dbeta[c] = (float)db;
+    }
+    // dy = A*dz + B*y + Cc
+    const double A = g * r;
+    const double B = -g * r * r * dg / (double)count;
+    const double Cc = -g * r * db / (double)count + g * r * r * mu * dg / (double)count;
+    coef[c] = (float)A;
+    coef[C + c] = (float)B;
+    coef[2 * C + c] = (float)Cc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// bilinear (align_corners=False) upsample + channel concat, and its transpose
+// ---------------------------------------------------------------------------------------
+struct CatArgs {
+  char* cat;
+  char* xs[4];
+  int hs[4], ws[4], cs[4], coff[4];
+  int nbr, N, H, W, Ctot, accumulate;
+};
+
+__device__ __forceinline__ void bilin_src(int d, int in_size, int out_size, int& i0, int& i1, float& l1) {
+  // PyTorch area_pixel_compute_source_index(align_corners=False): src = (d+0.5)*scale-0.5, clamp >= 0
+  const float scale = (float)in_size / (float)out_size;
+  float src = ((float)d + 0.5f) * scale - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_cat_kernel(CatArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const int cv = a.Ctot / VEC;
+  const long long total = (long long)a.N * a.H * a.W * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    long long pix = idx / cv;
+    const int ox = (int)(pix % a.W);
+    pix /= a.W;
+    const int oy = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    const int c = v * VEC;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < a.nbr && c >= a.coff[k]) b = k;
+    const int cl = c - a.coff[b];
+    const int hs = a.hs[b], ws = a.ws[b], cs = a.cs[b];
+    const char* src = a.xs[b];
+    float o[VEC];
+    if (hs == a.H && ws == a.W) {
+      v16_unpack<T>(*(const V16*)(src + ((size_t)((n * hs + oy) * ws + ox) * cs + cl) * sizeof(T)), o);
+    } else {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      bilin_src(oy, hs, a.H, y0, y1, ly);
+      bilin_src(ox, ws, a.W, x0, x1, lx);
+      float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+      const size_t base = (size_t)n * hs * ws;
+      v16_unpack<T>(*(const V16*)(src + ((base + (size_t)y0 * ws + x0) * cs + cl) * sizeof(T)), f00);
+      v16_unpack<T>(*(const V16*)(src + ((base + (size_t)y0 * ws + x1) * cs + cl) * sizeof(T)), f01);
+      v16_unpack<T>(*(const V16*)(src + ((base + (size_t)y1 * ws + x0) * cs + cl) * sizeof(T)), f10);
+      v16_unpack<T>(*(const V16*)(src + ((base + (size_t)y1 * ws + x1) * cs + cl) * sizeof(T)), f11);
+      const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        o[j] = hy * (hx * f00[j] + lx * f01[j]) + ly * (hx * f10[j] + lx * f11[j]);
+    }
+    *(V16*)(a.cat + (size_t)idx * 16) = v16_pack<T>(o);
+  }
+}
+
+// gather form of the transpose: one thread per (branch pixel, channel vector); loops over the
+// destination pixels whose bilinear footprint touches it and re-evaluates the forward weights.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_cat_bwd_kernel(CatArgs a, int b) {
+  constexpr int VEC = TT<T>::VEC;
+  const int hs = a.hs[b], ws = a.ws[b], cs = a.cs[b];
+  const int cv = cs / VEC;
+  const long long total = (long long)a.N * hs * ws * cv;
+  const int fy = (a.H + hs - 1) / hs, fx = (a.W + ws - 1) / ws;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    long long pix = idx / cv;
+    const int sx = (int)(pix % ws);
+    pix /= ws;
+    const int sy = (int)(pix % hs);
+    const int n = (int)(pix / hs);
+    const int c = v * VEC;
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+    if (hs == a.H && ws == a.W) {
+      v16_unpack<T>(*(const V16*)(a.cat + ((size_t)((n * a.H + sy) * a.W + sx) * a.Ctot + a.coff[b] + c) * sizeof(T)), o);
+    } else {
+      int dy0 = (sy - 1) * fy - 1, dy1 = (sy + 2) * fy + 1;
+      int dx0 = (sx - 1) * fx - 1, dx1 = (sx + 2) * fx + 1;
+      if (dy0 < 0) dy0 = 0;
+      if (dx0 < 0) dx0 = 0;
+      if (dy1 > a.H) dy1 = a.H;
+      if (dx1 > a.W) dx1 = a.W;
+      for (int dy = dy0; dy < dy1; ++dy) {
+        int y0, y1;
+        float ly;
+        bilin_src(dy, hs, a.H, y0, y1, ly);
+        const float wy = (y0 == sy ? 1.f - ly : 0.f) + (y1 == sy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int dx = dx0; dx < dx1; ++dx) {
+          int x0, x1;
+          float lx;
+          bilin_src(dx, ws, a.W, x0, x1, lx);
+          const float wx = (x0 == sx ? 1.f - lx : 0.f) + (x1 == sx ? lx : 0.f);
+          if (wx == 0.f) continue;
+          float gv[VEC];
+          v16_unpack<T>(*(const V16*)(a.cat + ((size_t)((n * a.H + dy) * a.W + dx) * a.Ctot + a.coff[b] + c) * sizeof(T)), gv);
+          const float w = wy * wx;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] = fmaf(w, gv[j], o[j]);
+        }
+      }
+    }
+    char* d = a.xs[b] + (size_t)idx * 16;
+    if (a.accumulate) {
+      float old[VEC];
+      v16_unpack<T>(*(const V16*)d, old);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += old[j];
+    }
+    *(V16*)d = v16_pack<T>(o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// stem im2col, layout conversions, weight packing, bias grad, wgrad slab reduction
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* img, T* cols, int N, int C,
+                                                          int H, int W, int Ho, int Wo, int Kpad) {
+  const long long total = (long long)N * Ho * Wo * Kpad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kpad);
+    long long pix = idx / Kpad;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float val = 0.f;
+    if (k < 9 * C) {
+      const int tap = k / C, c = k % C;
+      const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = img[((size_t)(n * C + c) * H + iy) * W + ix];
+    }
+    cols[idx] = (T)val;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* dst, int N, int HW,
+                                                           int Cp, int C) {
+  // 32 pixels x 32 channels tiles through LDS so both sides stay coalesced
+  __shared__ float tile[32][33];
+  const int pt = blockIdx.x * 32, ct = blockIdx.y * 32, n = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int p = pt + r, c = ct + tx;
+    tile[r][tx] = (p < HW && c < Cp) ? to_f32(src[((size_t)n * HW + p) * Cp + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = ct + r, p = pt + tx;
+    if (c < C && p < HW) dst[((size_t)n * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int N, int HW,
+                                                           int Cp, int C) {
+  __shared__ float tile[32][33];
+  const int pt = blockIdx.x * 32, ct = blockIdx.y * 32, n = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = ct + r, p = pt + tx;
+    tile[r][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = pt + r, c = ct + tx;
+    if (p < HW && c < Cp) dst[((size_t)n * HW + p) * Cp + c] = (T)tile[tx][r];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, T* out, int Cout, int Cin,
+                                                           int ks, int Cout_pad, int Cin_pad, int mode) {
+  const int taps = ks * ks;
+  const long long total = mode == 1 ? (long long)Cin_pad * taps * Cout_pad
+                                    : (mode == 2 ? (long long)Cout_pad * Cin_pad
+                                                 : (long long)Cout_pad * taps * Cin_pad);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    float val = 0.f;
+    if (mode == 0) {
+      const int ci = (int)(idx % Cin_pad);
+      const int t = (int)((idx / Cin_pad) % taps);
+      const int co = (int)(idx / ((long long)Cin_pad * taps));
+      if (co < Cout && ci < Cin) val = w[((size_t)co * Cin + ci) * taps + t];
+    } else if (mode == 1) {
+      // transposed conv: out[ci][taps-1-t][co] = w[co][ci][t]
+      const int co = (int)(idx % Cout_pad);
+      const int tf = (int)((idx / Cout_pad) % taps);
+      const int ci = (int)(idx / ((long long)Cout_pad * taps));
+      if (co < Cout && ci < Cin) val = w[((size_t)co * Cin + ci) * taps + (taps - 1 - tf)];
+    } else {
+      const int k = (int)(idx % Cin_pad);
+      const int co = (int)(idx / Cin_pad);
+      if (co < Cout && k < taps * Cin) {
+        const int t = k / Cin, ci = k % Cin;
+        val = w[((size_t)co * Cin + ci) * taps + t];
+      }
+    }
+    out[idx] = (T)val;
+  }
+}
+
+// column sums of dy[pixels][Cp] (conv bias gradient), two-stage and deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const char* dy, float* partial, long long pixels,
+                                                     int Cp) {
+  constexpr int VEC = TT<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int cv = Cp / VEC;
+  const int rows = 256 / cv;
+  const int v = threadIdx.x % cv, row = threadIdx.x / cv;
+  float s1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s1[j] = 0.f;
+  if (row < rows)
+    for (long long p = (long long)blockIdx.x * rows + row; p < pixels; p += (long long)gridDim.x * rows) {
+      float f[VEC];
+      v16_unpack<T>(*(const V16*)(dy + ((size_t)p * Cp + v * VEC) * sizeof(T)), f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s1[j] += f[j];
+    }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = s1[j];
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < Cp; ch += 256) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[(r * cv + ch / VEC) * VEC + ch % VEC];
+    partial[(size_t)blockIdx.x * Cp + ch] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* partial, float* dbias,
+                                                              int blocks, int Cp, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * Cp + c];
+  dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
+                                                           int Cout, int Cin, int ks, int Cout_real,
+                                                           int Cin_real, int kflat, int accumulate) {
+  const int taps = ks * ks;
+  const long long total = (long long)Cout_real * Cin_real * taps;
+  const size_t slab_sz = (size_t)Cout * (kflat ? 1 : taps) * Cin;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    // idx enumerates the slab order (co, tap, ci) so reads stay coalesced
+    const int ci = (int)(idx % Cin_real);
+    const int t = (int)((idx / Cin_real) % taps);
+    const int co = (int)(idx / ((long long)Cin_real * taps));
+    const size_t soff = kflat ? ((size_t)co * Cin + (size_t)t * Cin_real + ci)
+                              : (((size_t)co * taps + t) * Cin + ci);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[k * slab_sz + soff];
+    float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
+    *g = accumulate ? *g + s : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_zero_kernel(V16* p, long long n16, char* tail, int ntail) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = v16_zero();
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// launchers
+// =========================================================================================
+int hr_launch_bn_finalize(const HrOp& op, hipStream_t s) {
+  const int tiles = op.i[0], C = op.i[1], training = op.i[2];
+  HR_REQUIRE(C > 0, "bn_finalize: C=%d", C);
+  HR_REQUIRE(op.p[1] && op.p[2] && op.p[6] && op.p[7], "bn_finalize: null pointer");
+  HR_REQUIRE(training ? (op.p[0] != nullptr && tiles > 0) : (op.p[3] && op.p[4]),
+             "bn_finalize: missing statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)op.p[0],
+                     tiles, C, op.f[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
+                     (float*)op.p[4], (long long*)op.p[5], op.f[1], op.f[2], training, (float*)op.p[6],
+                     (float*)op.p[7], (float*)op.p[8], (float*)op.p[9]);
+  return hr_check_launch("bn_finalize");
+}
+
+int hr_launch_sum_terms(const HrOp& op, hipStream_t s) {
+  SumArgs a;
+  const int dtype = op.i[0];
+  a.N = op.i[1]; a.Ho = op.i[2]; a.Wo = op.i[3]; a.C = op.i[4]; a.nterms = op.i[5]; a.relu_out = op.i[6];
+  HR_REQUIRE(a.nterms >= 1 && a.nterms <= 4, "sum_terms: nterms=%d", a.nterms);
+  HR_REQUIRE(a.C % (dtype == HR_F32 ? 4 : 8) == 0, "sum_terms: C=%d", a.C);
+  a.out = (char*)op.p[0];
+  HR_REQUIRE(a.out, "sum_terms: null out");
+  for (int t = 0; t < 4; ++t) {
+    a.sh[t] = op.i[7 + t];
+    a.relu[t] = op.i[11 + t];
+    a.src[t] = (const char*)op.p[1 + t];
+    a.scale[t] = (const float*)op.p[5 + t];
+    a.shift[t] = (const float*)op.p[9 + t];
+    if (t < a.nterms) {
+      HR_REQUIRE(a.src[t], "sum_terms: null src %d", t);
+      HR_REQUIRE((a.Ho % (1 << a.sh[t])) == 0 && (a.Wo % (1 << a.sh[t])) == 0, "sum_terms: upsample shift");
+      HR_REQUIRE((a.scale[t] == nullptr) == (a.shift[t] == nullptr), "sum_terms: scale/shift pair");
+    }
+  }
+  const long long total = (long long)a.N * a.Ho * a.Wo * (a.C / (dtype == HR_F32 ? 4 : 8));
+  if (dtype == HR_F32)
+    hipLaunchKernelGGL(sum_terms_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(sum_terms_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  return hr_check_launch("sum_terms");
+}
+
+static int fill_grad_args(const HrOp& op, GradArgs& a, bool reduce) {
+  a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.sh = op.i[5]; a.inner_relu = op.i[6];
+  a.accumulate = reduce ? 0 : op.i[7];
+  if (reduce) {
+    a.partials = (float*)op.p[0]; a.dst = nullptr; a.coef = nullptr;
+  } else {
+    a.dst = (char*)op.p[0]; a.partials = nullptr; a.coef = (const float*)op.p[6];
+  }
+  a.g = (const char*)op.p[1]; a.mask = (const char*)op.p[2]; a.y = (const char*)op.p[3];
+  a.scale = (const float*)op.p[4]; a.shift = (const float*)op.p[5];
+  HR_REQUIRE(op.p[0] && a.g, "grad_term: null pointer");
+  HR_REQUIRE(a.sh >= 0 && a.sh <= 4, "grad_term: shift %d", a.sh);
+  HR_REQUIRE(!(a.inner_relu || a.coef || reduce) || a.y, "grad_term: y required");
+  HR_REQUIRE(a.C % (op.i[0] == HR_F32 ? 4 : 8) == 0, "grad_term: C=%d", a.C);
+  return 0;
+}
+
+int hr_launch_grad_term(const HrOp& op, hipStream_t s) {
+  GradArgs a;
+  if (int e = fill_grad_args(op, a, false)) return e;
+  const long long total = (long long)a.N * a.H * a.W * (a.C / (op.i[0] == HR_F32 ? 4 : 8));
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(grad_term_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(grad_term_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  return hr_check_launch("grad_term");
+}
+
+extern "C" int hrnet_reduce_blocks(int N, int H, int W, int C) {
+  const long long npix = (long long)N * H * W;
+  long long b = npix / 64;
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  (void)C;
+  return (int)b;
+}
+
+int hr_launch_bn_bwd_reduce(const HrOp& op, hipStream_t s) {
+  GradArgs a;
+  if (int e = fill_grad_args(op, a, true)) return e;
+  const int vec = op.i[0] == HR_F32 ? 4 : 8;
+  HR_REQUIRE(a.C / vec <= 256, "bn_bwd_reduce: C=%d too wide", a.C);
+  const int blocks = hrnet_reduce_blocks(a.N, a.H, a.W, a.C);
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  return hr_check_launch("bn_bwd_reduce");
+}
+
+int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s) {
+  const int blocks = op.i[0], C = op.i[1];
+  HR_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6],
+             "bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)op.p[0],
+                     blocks, C, op.f[0], (const float*)op.p[1], (const float*)op.p[2],
+                     (const float*)op.p[3], (float*)op.p[4], (float*)op.p[5], (float*)op.p[6], op.i[2]);
+  return hr_check_launch("bn_bwd_finalize");
+}
+
+static int fill_cat_args(const HrOp& op, CatArgs& a, bool bwd) {
+  a.nbr = op.i[1]; a.N = op.i[2]; a.H = op.i[3]; a.W = op.i[4];
+  HR_REQUIRE(a.nbr >= 1 && a.nbr <= 4, "bilinear_cat: nbr=%d", a.nbr);
+  a.cat = (char*)op.p[0];
+  HR_REQUIRE(a.cat, "bilinear_cat: null cat");
+  int off = 0;
+  const int vec = op.i[0] == HR_F32 ? 4 : 8;
+  for (int k = 0; k < 4; ++k) {
+    a.hs[k] = op.i[5 + k]; a.ws[k] = op.i[9 + k]; a.cs[k] = op.i[13 + k];
+    a.xs[k] = (char*)op.p[1 + k];
+    a.coff[k] = off;
+    if (k < a.nbr) {
+      HR_REQUIRE(a.xs[k] && a.cs[k] % vec == 0 && a.hs[k] > 0 && a.ws[k] > 0, "bilinear_cat: branch %d", k);
+      off += a.cs[k];
+    }
+  }
+  a.Ctot = off;
+  a.accumulate = bwd ? op.i[17] : 0;
+  return 0;
+}
+
+int hr_launch_bilinear_cat(const HrOp& op, hipStream_t s) {
+  CatArgs a;
+  if (int e = fill_cat_args(op, a, false)) return e;
+  const long long total = (long long)a.N * a.H * a.W * (a.Ctot / (op.i[0] == HR_F32 ? 4 : 8));
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(bilinear_cat_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(bilinear_cat_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  return hr_check_launch("bilinear_cat");
+}
+
+int hr_launch_bilinear_cat_bwd(const HrOp& op, hipStream_t s) {
+  CatArgs a;
+  if (int e = fill_cat_args(op, a, true)) return e;
+  for (int b = 0; b < a.nbr; ++b) {
+    const long long total = (long long)a.N * a.hs[b] * a.ws[b] * (a.cs[b] / (op.i[0] == HR_F32 ? 4 : 8));
+    if (op.i[0] == HR_F32)
+      hipLaunchKernelGGL(bilinear_cat_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, a, b);
+    else
+      hipLaunchKernelGGL(bilinear_cat_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a, b);
+  }
+  return hr_check_launch("bilinear_cat_bwd");
+}
+
+int hr_launch_im2col_stem(const HrOp& op, hipStream_t s) {
+  const int N = op.i[1], C = op.i[2], H = op.i[3], W = op.i[4], Ho = op.i[5], Wo = op.i[6], Kpad = op.i[7];
+  HR_REQUIRE(op.p[0] && op.p[1], "im2col_stem: null pointer");
+  HR_REQUIRE(Kpad >= 9 * C && Ho == (H + 1) / 2 && Wo == (W + 1) / 2, "im2col_stem: shape");
+  const long long total = (long long)N * Ho * Wo * Kpad;
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(im2col_stem_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       (const float*)op.p[0], (float*)op.p[1], N, C, H, W, Ho, Wo, Kpad);
+  else
+    hipLaunchKernelGGL(im2col_stem_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       (const float*)op.p[0], (bf16_t*)op.p[1], N, C, H, W, Ho, Wo, Kpad);
+  return hr_check_launch("im2col_stem");
+}
+
+int hr_launch_nhwc_to_nchw(const HrOp& op, hipStream_t s) {
+  const int N = op.i[1], HW = op.i[2] * op.i[3], Cp = op.i[4], C = op.i[5];
+  HR_REQUIRE(op.p[0] && op.p[1] && C <= Cp, "nhwc_to_nchw: args");
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)op.p[0],
+                       (float*)op.p[1], N, HW, Cp, C);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)op.p[0],
+                       (float*)op.p[1], N, HW, Cp, C);
+  return hr_check_launch("nhwc_to_nchw");
+}
+
+int hr_launch_nchw_to_nhwc(const HrOp& op, hipStream_t s) {
+  const int N = op.i[1], HW = op.i[2] * op.i[3], Cp = op.i[4], C = op.i[5];
+  HR_REQUIRE(op.p[0] && op.p[1] && C <= Cp, "nchw_to_nhwc: args");
+  dim3 grid((HW + 31) / 32, (Cp + 31) / 32, N);
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, (const float*)op.p[0],
+                       (float*)op.p[1], N, HW, Cp, C);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, s, (const float*)op.p[0],
+                       (bf16_t*)op.p[1], N, HW, Cp, C);
+  return hr_check_launch("nchw_to_nhwc");
+}
+
+int hr_launch_pack_weights(const HrOp& op, hipStream_t s) {
+  const int Cout = op.i[1], Cin = op.i[2], ks = op.i[3], Cout_pad = op.i[4], Cin_pad = op.i[5], mode = op.i[6];
+  HR_REQUIRE(op.p[0] && op.p[1] && mode >= 0 && mode <= 2, "pack_weights: args");
+  HR_REQUIRE(Cout_pad >= Cout && (mode == 2 ? Cin_pad >= Cin * ks * ks : Cin_pad >= Cin), "pack_weights: pads");
+  const long long total = mode == 2 ? (long long)Cout_pad * Cin_pad : (long long)Cout_pad * ks * ks * Cin_pad;
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       (const float*)op.p[0], (float*)op.p[1], Cout, Cin, ks, Cout_pad, Cin_pad, mode);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       (const float*)op.p[0], (bf16_t*)op.p[1], Cout, Cin, ks, Cout_pad, Cin_pad, mode);
+  return hr_check_launch("pack_weights");
+}
+
+int hr_launch_bias_grad(const HrOp& op, hipStream_t s) {
+  const int pixels = op.i[1], Cp = op.i[2], C = op.i[3];
+  const int vec = op.i[0] == HR_F32 ? 4 : 8;
+  HR_REQUIRE(op.p[0] && op.p[1] && op.p[2] && C <= Cp && Cp % vec == 0 && Cp / vec <= 256, "bias_grad: args");
+  const int blocks = hrnet_reduce_blocks(1, 1, pixels, Cp);
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, s, (const char*)op.p[0],
+                       (float*)op.p[2], (long long)pixels, Cp);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const char*)op.p[0],
+                       (float*)op.p[2], (long long)pixels, Cp);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)op.p[2],
+                     (float*)op.p[1], blocks, Cp, C, op.i[4]);
+  return hr_check_launch("bias_grad");
+}
+
+int hr_launch_wgrad_reduce(const HrOp& op, hipStream_t s) {
+  const int nsplit = op.i[0], Cout = op.i[1], Cin = op.i[2], ks = op.i[3], Cout_real = op.i[4],
+            Cin_real = op.i[5], kflat = op.i[6];
+  HR_REQUIRE(op.p[0] && op.p[1] && nsplit >= 1, "wgrad_reduce: args");
+  HR_REQUIRE(Cout_real <= Cout && (kflat ? Cin_real * ks * ks <= Cin : Cin_real <= Cin), "wgrad_reduce: extents");
+  const long long total = (long long)Cout_real * Cin_real * ks * ks;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)op.p[0],
+                     (float*)op.p[1], nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, op.i[7]);
+  return hr_check_launch("wgrad_reduce");
+}
+
+int hr_launch_fill(const HrOp& op, hipStream_t s) {
+  const long long bytes = ((long long)(uint32_t)op.i[1] << 32) | (uint32_t)op.i[0];
+  HR_REQUIRE(op.p[0] && bytes >= 0 && ((uintptr_t)op.p[0] % 16) == 0, "fill_zero: args");
+  const long long n16 = bytes / 16;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(ew_grid(n16 > 0 ? n16 : 1)), dim3(256), 0, s, (V16*)op.p[0],
+                     n16, (char*)op.p[0] + n16 * 16, (int)(bytes % 16));
+  return hr_check_launch("fill_zero");
+}

@@ -1,0 +1,261 @@
+// Weight gradient on MFMA for gfx950.
+//
+//   dW[co][tap][ci] = sum_{n, oy, ox} dY[n,oy,ox,co] * Xa[n, oy*S - pad + r, ox*S - pad + s, ci]
+//
+// The contraction index is the PIXEL, which is the slow axis of both NHWC operands. bf16 uses
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read: 4 pixels x 16 channels delivered
+// channel-per-lane) so the same NHWC halo image the forward conv uses feeds the MFMA without a
+// transposed copy; f32 uses the one-value-per-lane 16x16x4 operand form (4 ds_read_b32).
+//
+// A workgroup owns BCO output channels x (all taps) x KC input channels and loops over its
+// share of the pixel tiles, accumulating in registers; each of the 4 waves owns a fixed subset
+// of the (tap, ci-fragment) x co-fragment outputs, so there is no cross-wave reduction. It then
+// writes one f32 slab; hrnet_wgrad_reduce sums the slabs in a fixed order (bitwise
+// reproducible, no float atomics).
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  const char* x;
+  const char* dy;
+  const float* in_scale;
+  const float* in_shift;
+  float* slabs;
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int tiles_y, tiles_x, total_tiles;
+  int in_relu;
+};
+
+// lane's KSTEP-deep operand fragment for 16 channels starting at byte offset `choff` of each
+// pixel row; r0 = LDS byte address of the lane group's first pixel, rstep = byte distance between
+// consecutive pixels of the group.
+template <typename T>
+__device__ __forceinline__ V16 tr_load(const char* base, int r0, int rstep, int choff, int lane);
+
+template <>
+__device__ __forceinline__ V16 tr_load<bf16_t>(const char* base, int r0, int rstep, int choff,
+                                               int lane) {
+  // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3; lane i
+  // receives column i of the 4 rows. Two reads cover the group's 8 pixels.
+  const int q = (lane & 15) >> 2, p4 = lane & 3;
+  const int addr = r0 + q * rstep + choff + p4 * 8;
+  const LDS_AS char* l = (const LDS_AS char*)base;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + addr));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + addr + 4 * rstep));
+  const bf16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(V16, v);
+}
+
+template <>
+__device__ __forceinline__ V16 tr_load<float>(const char* base, int r0, int rstep, int choff,
+                                              int lane) {
+  const char* p = base + r0 + choff + (lane & 15) * 4;
+  return V16{*(const uint32_t*)p, *(const uint32_t*)(p + rstep), *(const uint32_t*)(p + 2 * rstep),
+             *(const uint32_t*)(p + 3 * rstep)};
+}
+
+template <typename T, int KS, int STRIDE, int TH, int TW, int BCO, int KC, int WCO, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  constexpr int KSTEP = TT<T>::KSTEP;
+  constexpr int TAPS = KS * KS;
+  constexpr int HALO_H = (TH - 1) * STRIDE + KS;
+  constexpr int HALO_W = (TW - 1) * STRIDE + KS;
+  constexpr int PIXB = KC * (int)sizeof(T) + 16;
+  constexpr int DYB = BCO * (int)sizeof(T) + 16;
+  constexpr int XBYTES = HALO_H * HALO_W * PIXB;
+  constexpr int BM = TH * TW;
+  constexpr int FCO = BCO / 16, FCI = KC / 16;
+  constexpr int FCOW = FCO / WCO;            // co fragments per wave
+  constexpr int NFR = TAPS * FCI;            // (tap, ci-fragment) outputs
+  constexpr int NPW = (NFR + WN - 1) / WN;   // of which per wave
+  constexpr int DVPP = BCO / VEC;            // 16-byte vectors per dY pixel
+  static_assert(WCO * WN == 4 && FCO % WCO == 0, "wave grid");
+  static_assert(BM % KSTEP == 0 && TW % VEC == 0, "pixel groups stay inside a tile row");
+  __shared__ __attribute__((aligned(16))) char lds[XBYTES + BM * DYB];
+  char* xl = lds;
+  char* dl = lds + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave % WCO, wn = wave / WCO;
+  const int li = lane & 15, lg = lane >> 4;
+  const int co0 = blockIdx.y * BCO, c0 = blockIdx.z * KC;
+  constexpr int PAD = KS / 2;
+
+  // this wave's (tap, ci-fragment) list
+  int tapb[NPW], cib[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int f = wn + WN * j;
+    const int t = f / FCI, fci = f % FCI;
+    tapb[j] = ((t / KS) * HALO_W + (t % KS)) * PIXB;
+    cib[j] = fci * 16 * (int)sizeof(T);
+  }
+
+  f32x4 acc[NPW][FCOW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j)
+#pragma unroll
+    for (int f = 0; f < FCOW; ++f) acc[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    stage_halo<T, KC, HALO_H, HALO_W, PIXB>(xl, a.x, n, a.H, a.W, a.Cin, a.H, a.W,
+                                            ty * TH * STRIDE - PAD, tx * TW * STRIDE - PAD, c0,
+                                            a.in_scale, a.in_shift, a.in_relu, 0, tid);
+    for (int idx = tid; idx < BM * DVPP; idx += 256) {
+      const int p = idx / DVPP, v = idx % DVPP;
+      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      const int co = co0 + v * VEC;
+      V16 val = v16_zero();
+      if (oy < a.Ho && ox < a.Wo && co < a.Cout)
+        val = *(const V16*)(a.dy + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * sizeof(T));
+      *(V16*)(dl + p * DYB + v * 16) = val;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < BM / KSTEP; ++ks) {
+      const int p0 = ks * KSTEP + lg * VEC;  // first pixel of this lane group
+      const int py = p0 / TW, px = p0 % TW;
+      const int xr0 = ((py * STRIDE) * HALO_W + px * STRIDE) * PIXB;
+      V16 af[FCOW];
+#pragma unroll
+      for (int f = 0; f < FCOW; ++f)
+        af[f] = tr_load<T>(dl, p0 * DYB, DYB, (wco * FCOW + f) * 16 * (int)sizeof(T), lane);
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        if (wn + WN * j < NFR) {
+          const V16 bf = tr_load<T>(xl, xr0 + tapb[j], STRIDE * PIXB, cib[j], lane);
+#pragma unroll
+          for (int f = 0; f < FCOW; ++f) acc[j][f] = mma16<T>(af[f], bf, acc[j][f]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // slab[split][co][tap][ci]; D layout: col (lane&15) = ci, row 4*(lane>>4)+r = co
+  float* slab = a.slabs + (size_t)blockIdx.x * a.Cout * TAPS * a.Cin;
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int fr = wn + WN * j;
+    if (fr < NFR) {
+      const int t = fr / FCI, ci = c0 + (fr % FCI) * 16 + li;
+#pragma unroll
+      for (int f = 0; f < FCOW; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wco * FCOW + f) * 16 + lg * 4 + r;
+          if (co < a.Cout && ci < a.Cin) slab[((size_t)co * TAPS + t) * a.Cin + ci] = acc[j][f][r];
+        }
+    }
+  }
+}
+
+struct WgCfg {
+  int th, tw, bco, kc, id;
+};
+
+WgCfg choose_wg(int dtype, int Ho, int Wo, int Cout, int ks, int stride) {
+  const bool f32 = dtype == HR_F32;
+  if (ks == 1) return f32 ? WgCfg{8, 16, 64, 32, 10} : WgCfg{8, 16, 64, 64, 10};
+  const bool big = Ho >= 16 && Wo >= 16 && stride == 1;
+  const int kc = f32 ? 16 : 32;
+  if (Cout <= 32) return big ? WgCfg{16, 16, 32, kc, 0} : WgCfg{8, 8, 32, kc, 1};
+  return big ? WgCfg{16, 16, 64, kc, 2} : WgCfg{8, 8, 64, kc, 3};
+}
+
+template <typename T, int KC3, int KC1>
+int launch_wg(const WgradArgs& a, const WgCfg& c, int ks, int stride, dim3 grid, hipStream_t s) {
+#define WG(KS_, ST_, TH_, TW_, BCO_, KC_, WCO_, WN_) \
+  hipLaunchKernelGGL((wgrad_kernel<T, KS_, ST_, TH_, TW_, BCO_, KC_, WCO_, WN_>), grid, dim3(256), 0, s, a)
+  if (ks == 1) {
+    WG(1, 1, 8, 16, 64, KC1, 2, 2);
+  } else if (stride == 1) {
+    switch (c.id) {
+      case 0: WG(3, 1, 16, 16, 32, KC3, 1, 4); break;
+      case 1: WG(3, 1, 8, 8, 32, KC3, 1, 4); break;
+      case 2: WG(3, 1, 16, 16, 64, KC3, 2, 2); break;
+      default: WG(3, 1, 8, 8, 64, KC3, 2, 2); break;
+    }
+  } else {
+    if (c.bco == 32) WG(3, 2, 8, 8, 32, KC3, 1, 4);
+    else WG(3, 2, 8, 8, 64, KC3, 2, 2);
+  }
+#undef WG
+  return hr_check_launch("conv2d_wgrad");
+}
+
+}  // namespace
+
+extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks,
+                                  int stride) {
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  const int tiles = N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
+  const int gy = (Cout + c.bco - 1) / c.bco;
+  const int gz = (Cin + c.kc - 1) / c.kc;
+  int ns = 768 / (gy * gz);
+  if (ns < 1) ns = 1;
+  if (ns > 128) ns = 128;
+  if (ns > tiles) ns = tiles;
+  return ns;
+}
+
+int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
+  const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cin = op.i[4], Ho = op.i[5],
+            Wo = op.i[6], Cout = op.i[7], ks = op.i[8], stride = op.i[9], nsplit = op.i[11];
+  HR_REQUIRE(dtype == HR_F32 || dtype == HR_BF16, "wgrad: bad dtype %d", dtype);
+  HR_REQUIRE(ks == 1 || ks == 3, "wgrad: kernel size %d", ks);
+  HR_REQUIRE(stride == 1 || (stride == 2 && ks == 3), "wgrad: stride %d", stride);
+  HR_REQUIRE(Cin % (dtype == HR_F32 ? 4 : 8) == 0 && Cout % (dtype == HR_F32 ? 4 : 8) == 0,
+             "wgrad: channel counts must be 16-byte multiples (Cin=%d Cout=%d)", Cin, Cout);
+  HR_REQUIRE(nsplit >= 1, "wgrad: nsplit=%d", nsplit);
+  HR_REQUIRE(op.p[0] && op.p[1] && op.p[4], "wgrad: null pointer");
+  const int pad = ks / 2;
+  HR_REQUIRE((H + 2 * pad - ks) / stride + 1 == Ho && (W + 2 * pad - ks) / stride + 1 == Wo,
+             "wgrad: shape mismatch");
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  WgradArgs a;
+  a.x = (const char*)op.p[0];
+  a.dy = (const char*)op.p[1];
+  a.in_scale = (const float*)op.p[2];
+  a.in_shift = (const float*)op.p[3];
+  a.slabs = (float*)op.p[4];
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.tiles_y = (Ho + c.th - 1) / c.th;
+  a.tiles_x = (Wo + c.tw - 1) / c.tw;
+  a.total_tiles = N * a.tiles_y * a.tiles_x;
+  a.in_relu = op.i[10];
+  dim3 grid((unsigned)nsplit, (unsigned)((Cout + c.bco - 1) / c.bco), (unsigned)((Cin + c.kc - 1) / c.kc));
+  if (dtype == HR_F32) return launch_wg<float, 16, 32>(a, c, ks, stride, grid, s);
+  return launch_wg<bf16_t, 32, 64>(a, c, ks, stride, grid, s);
+}
+
+extern "C" int hrnet_conv2d_wgrad(int dtype, const void* x, const void* dy, const float* in_scale,
+                                  const float* in_shift, float* slabs, int N, int H, int W, int Cin,
+                                  int Ho, int Wo, int Cout, int ks, int stride, int in_relu,
+                                  int nsplit, hr_stream_t stream) {
+  HrOp op = {};
+  op.kind = HR_OP_WGRAD;
+  const int iv[12] = {dtype, N, H, W, Cin, Ho, Wo, Cout, ks, stride, in_relu, nsplit};
+  for (int k = 0; k < 12; ++k) op.i[k] = iv[k];
+  op.p[0] = (void*)x; op.p[1] = (void*)dy; op.p[2] = (void*)in_scale; op.p[3] = (void*)in_shift;
+  op.p[4] = slabs;
+  return hr_launch_wgrad(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf,
+                                       int buflen) {
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  int wco = 2, wn = 2;
+  if (ks == 3 && c.bco == 32) { wco = 1; wn = 4; }
+  return snprintf(buf, buflen, "wgrad_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",
+                  ks, stride, c.th, c.tw, c.bco, c.kc, wco, wn);
+}

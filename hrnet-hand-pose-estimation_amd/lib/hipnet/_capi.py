@@ -1,0 +1,116 @@
+"""ctypes binding of libhrnet_hip.so (the C ABI declared in include/hrnet_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised. The product path never computes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(os.path.dirname(_HERE))
+LIB_PATH = os.environ.get('HRNET_HIP_LIB', os.path.join(_PKG, 'csrc', 'libhrnet_hip.so'))
+
+HR_F32, HR_BF16 = 0, 1
+
+(OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_BN_FINALIZE, OP_SUM_TERMS, OP_GRAD_TERM, OP_BN_BWD_REDUCE,
+ OP_BN_BWD_FINALIZE, OP_BILINEAR_CAT, OP_BILINEAR_CAT_BWD, OP_IM2COL_STEM, OP_NHWC_TO_NCHW,
+ OP_NCHW_TO_NHWC, OP_PACK_WEIGHTS, OP_BIAS_GRAD, OP_FILL) = range(1, 17)
+
+
+class HrOp(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('i', ctypes.c_int32 * 19), ('f', ctypes.c_float * 4),
+                ('p', ctypes.c_void_p * 14)]
+
+
+_c_int, _c_float, _c_vp, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> argument ctypes (all return int unless listed in _RET)
+_SIGS = {
+    'hrnet_abi_version': [],
+    'hrnet_program_run': [ctypes.POINTER(HrOp), _c_int, _c_vp],
+    'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
+    'hrnet_conv_tiles': [_c_int] * 6,
+    'hrnet_conv_kernel_name': [_c_int] * 7 + [ctypes.c_char_p, _c_int],
+    'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
+    'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
+    'hrnet_wgrad_splits': [_c_int] * 8,
+    'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],
+    'hrnet_pack_weights': [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
+    'hrnet_bn_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 5 + [_c_float, _c_float, _c_int]
+                         + [_c_vp] * 4 + [_c_vp],
+    'hrnet_sum_terms': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_vp],
+    'hrnet_grad_term': [_c_int] + [_c_vp] * 7 + [_c_int] * 7 + [_c_vp],
+    'hrnet_bn_bwd_reduce': [_c_int] + [_c_vp] * 6 + [_c_int] * 6 + [_c_vp],
+    'hrnet_reduce_blocks': [_c_int] * 4,
+    'hrnet_bn_bwd_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 6 + [_c_int, _c_vp],
+    'hrnet_bilinear_cat': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 4 + [_c_vp],
+    'hrnet_bilinear_cat_bwd': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 5 + [_c_vp],
+    'hrnet_im2col_stem': [_c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
+    'hrnet_nhwc_to_nchw': [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp],
+    'hrnet_nchw_to_nhwc': [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp],
+    'hrnet_bias_grad': [_c_int, _c_vp, _c_vp, _c_vp] + [_c_int] * 4 + [_c_vp],
+    'hrnet_fill_zero': [_c_vp, _c_i64, _c_vp],
+    'hrnet_heatmap_loss_fwd': [_c_vp] * 4 + [_c_int] * 3 + [_c_vp],
+    'hrnet_heatmap_loss_bwd': [_c_vp] * 4 + [_c_int] * 3 + [_c_vp],
+    'hrnet_decode_expectation': [_c_vp, _c_vp] + [_c_int] * 3 + [_c_vp],
+    'hrnet_decode_expectation_bwd': [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp],
+    'hrnet_decode_argmax': [_c_vp] * 3 + [_c_int] * 4 + [_c_vp],
+    'hrnet_joints_loss_fwd': [_c_vp] * 4 + [_c_int] * 2 + [_c_vp],
+    'hrnet_joints_loss_bwd': [_c_vp] * 5 + [_c_int] * 2 + [_c_vp],
+    'hrnet_adam_step': [_c_vp] * 4 + [_c_i64] + [_c_float] * 5 + [_c_int, _c_float, _c_vp],
+}
+# plain-int helpers (no error code semantics)
+_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
+          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name'}
+EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string'])
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libhrnet_hip.so not found at {} - build it with `python __graft_entry__.py` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(LIB_PATH))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        l.hrnet_last_error_string.argtypes = []
+        l.hrnet_last_error_string.restype = ctypes.c_char_p
+        _lib = l
+    return _lib
+
+
+def call(name, *args):
+    """Call an entry point; negative return -> RuntimeError(hrnet_last_error_string())."""
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if name not in _PLAIN and rc != 0:
+        raise RuntimeError('{} failed ({}): {}'.format(name, rc, l.hrnet_last_error_string().decode()))
+    return rc
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_id(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return HR_F32
+    if torch_dtype == torch.bfloat16:
+        return HR_BF16
+    raise ValueError('unsupported compute dtype {}'.format(torch_dtype))

@@ -1,0 +1,486 @@
+"""Plan builder + executor for the HRNet hot path on MI355X.
+
+The model module (models/pose_hrnet.py) owns PyTorch parameters with the reference's
+state_dict names; this file turns (parameters, input shape, mode) into two recorded programs
+of C-ABI ops (forward, backward) over NHWC device buffers and runs each with ONE host call
+(hrnet_program_run). PyTorch is only the allocator / stream / autograd anchor.
+
+Dataflow conventions
+  Act   a device tensor [N,H,W,C] in the compute dtype. A conv output followed by BatchNorm is
+        stored RAW (pre-BN); its consumers apply scale/shift(+ReLU) while loading, so the
+        normalised tensor never makes an HBM round trip (reference: 7 separate kernels per
+        BasicBlock, lib/models/pose_hrnet.py:41-57).
+  Val   (act, bn, relu): the logical value relu?(bn?(act)) a consumer reads.
+  Grad  every Act has a gradient buffer. For a raw+BN act it first accumulates the gradient
+        w.r.t. the post-activation value, then BatchNorm backward rewrites it in place into the
+        gradient w.r.t. the raw conv output (two-stage deterministic reductions).
+"""
+import ctypes
+
+import torch
+
+from . import _capi as C
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act(object):
+    __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse')
+
+    def __init__(self, name, N, H, W, Cc):
+        self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cc
+        self.t = None       # torch tensor (storage)
+        self.g = None       # gradient tensor
+        self.ginit = False  # gradient buffer written yet (while recording the backward)
+        self.bn = None      # BNRec if this is a raw conv output followed by BatchNorm
+        self.bn_done = False
+        self.nuse = 0       # number of consumers of the logical value
+
+    @property
+    def pixels(self):
+        return self.N * self.H * self.W
+
+
+class Val(object):
+    __slots__ = ('act', 'bn', 'relu')
+
+    def __init__(self, act, bn=None, relu=False):
+        self.act, self.bn, self.relu = act, bn, relu
+
+
+class BNRec(object):
+    def __init__(self, prefix, mod, dev):
+        self.prefix = prefix
+        self.mod = mod
+        c = mod.num_features
+        self.C = c
+        f = dict(dtype=torch.float32, device=dev)
+        self.scale = torch.empty(c, **f)
+        self.shift = torch.empty(c, **f)
+        self.mean = torch.empty(c, **f)
+        self.invstd = torch.empty(c, **f)
+        self.coef = torch.empty(3 * c, **f)
+
+
+class ConvRec(object):
+    def __init__(self, prefix, mod, stem=False):
+        self.prefix, self.mod, self.stem = prefix, mod, stem
+        w = mod.weight
+        self.Cout, self.Cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
+        self.Cout_pad = _round_up(self.Cout, 16)
+        self.Cin_pad = 32 if stem else _round_up(self.Cin, 8)
+        self.wf = None   # packed forward weights
+        self.wd = None   # packed dgrad weights
+
+
+class Program(object):
+    """A recorded list of HrOp, run with one C call."""
+
+    def __init__(self):
+        self.ops = []
+        self._arr = None
+
+    def add(self, kind, ints=(), floats=(), ptrs=()):
+        op = C.HrOp()
+        op.kind = kind
+        for k, v in enumerate(ints):
+            op.i[k] = int(v)
+        for k, v in enumerate(floats):
+            op.f[k] = float(v)
+        for k, v in enumerate(ptrs):
+            op.p[k] = v
+        self.ops.append(op)
+        self._arr = None
+        return len(self.ops) - 1
+
+    def finalize(self):
+        self._arr = (C.HrOp * len(self.ops))(*self.ops)
+        return self
+
+    def set_ptr(self, op_index, slot, value):
+        self._arr[op_index].p[slot] = value
+
+    def set_int(self, op_index, slot, value):
+        self._arr[op_index].i[slot] = value
+
+    def run(self, lo=0, hi=None):
+        if self._arr is None:
+            self.finalize()
+        hi = len(self.ops) if hi is None else hi
+        if hi > lo:
+            base = ctypes.cast(ctypes.byref(self._arr, lo * ctypes.sizeof(C.HrOp)), ctypes.POINTER(C.HrOp))
+            C.call('hrnet_program_run', base, hi - lo, C.stream_ptr())
+
+    def __len__(self):
+        return len(self.ops)
+
+
+class Plan(object):
+    """Forward (+ backward) programs of one (batch, height, width, mode) instance."""
+
+    def __init__(self, net, N, H, W, training, need_grad):
+        self.net = net
+        self.N, self.H, self.W = N, H, W
+        self.training, self.need_grad = training, need_grad
+        self.dev = net.device
+        self.dt = net.compute_dtype
+        self.dtid = C.dtype_id(self.dt)
+        self.esize = 4 if self.dt == torch.float32 else 2
+        self.fwd = Program()
+        self.bwd = Program()
+        self.pack_f = Program()   # master f32 OIHW -> packed forward weights
+        self.pack_d = Program()   # -> packed dgrad weights
+        self.keep = []            # tensors kept alive
+        self.tape = []
+        self.acts = []
+        self.max_stats = 0
+        self.max_slab = 0
+        self.max_bwd_part = 0
+        self.pending = []         # (program, op_index, slot, kind) scratch pointers to patch
+        self.bucket_marks = []    # backward op indices after which a gradient bucket is complete
+        self._build()
+
+    # ---- allocation helpers -----------------------------------------------------------
+    def _act(self, name, N, H, W, Cc, grad=True):
+        a = Act(name, N, H, W, Cc)
+        a.t = torch.empty(N * H * W * Cc * self.esize, dtype=torch.uint8, device=self.dev)
+        if self.need_grad and grad:
+            a.g = torch.empty(N * H * W * Cc * self.esize, dtype=torch.uint8, device=self.dev)
+        self.acts.append(a)
+        return a
+
+    def _f32(self, n, zero=False):
+        t = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def _scratch(self, prog, idx, slot, kind):
+        self.pending.append((prog, idx, slot, kind))
+
+    # ---- forward recording -------------------------------------------------------------
+    def conv(self, xin, crec, stride=1, bnrec=None, relu=False, name=None):
+        """conv (+bias) [+ BatchNorm statistics]; returns the Val consumers read."""
+        x = xin.act
+        ks = 1 if crec.stem else crec.ks
+        Ho = (x.H + 2 * (ks // 2) - ks) // stride + 1
+        Wo = (x.W + 2 * (ks // 2) - ks) // stride + 1
+        y = self._act(name or crec.prefix, x.N, Ho, Wo, crec.Cout_pad)
+        cin = x.C
+        assert cin == crec.Cin_pad, (crec.prefix, cin, crec.Cin_pad)
+        want_stats = bnrec is not None and self.training
+        tiles = C.call('hrnet_conv_tiles', x.N, Ho, Wo, crec.Cout_pad, ks, stride)
+        bias = crec.mod.bias
+        i = self.fwd.add(C.OP_CONV,
+                         ints=(self.dtid, x.N, x.H, x.W, cin, Ho, Wo, crec.Cout_pad, ks, stride, 0,
+                               1 if xin.relu else 0, 0),
+                         ptrs=(C.ptr(x.t), C.ptr(crec.wf), C.ptr(xin.bn.scale) if xin.bn else None,
+                               C.ptr(xin.bn.shift) if xin.bn else None,
+                               C.ptr(self.net.bias_pad[crec.prefix]) if bias is not None else None,
+                               C.ptr(y.t), None))
+        if want_stats:
+            self.max_stats = max(self.max_stats, tiles * 2 * crec.Cout_pad)
+            self._scratch(self.fwd, i, 6, 'stats')
+        x.nuse += 1
+        if bnrec is not None:
+            y.bn = bnrec
+            if self.training:
+                m = bnrec.mod
+                j = self.fwd.add(C.OP_BN_FINALIZE, ints=(tiles, bnrec.C, 1),
+                                 floats=(y.pixels, m.momentum if m.momentum is not None else 0.1, m.eps),
+                                 ptrs=(None, C.ptr(m.weight), C.ptr(m.bias), C.ptr(m.running_mean),
+                                       C.ptr(m.running_var), C.ptr(m.num_batches_tracked), C.ptr(bnrec.scale),
+                                       C.ptr(bnrec.shift), C.ptr(bnrec.mean), C.ptr(bnrec.invstd)))
+                self._scratch(self.fwd, j, 0, 'stats')
+        self.tape.append(('conv', xin, crec, stride, y, bnrec))
+        return Val(y, bnrec, relu)
+
+    def sum(self, terms, shifts, relu_out, name):
+        t0 = terms[0].act
+        sh0 = shifts[0]
+        out = self._act(name, t0.N, t0.H << sh0, t0.W << sh0, t0.C)
+        ints = [self.dtid, out.N, out.H, out.W, out.C, len(terms), 1 if relu_out else 0]
+        ints += list(shifts) + [0] * (4 - len(terms))
+        ints += [1 if t.relu else 0 for t in terms] + [0] * (4 - len(terms))
+        ptrs = [C.ptr(out.t)]
+        ptrs += [C.ptr(t.act.t) for t in terms] + [None] * (4 - len(terms))
+        ptrs += [C.ptr(t.bn.scale) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+        ptrs += [C.ptr(t.bn.shift) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+        self.fwd.add(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
+        for t in terms:
+            t.act.nuse += 1
+        self.tape.append(('sum', list(terms), list(shifts), relu_out, out))
+        return Val(out)
+
+    def bilinear_cat(self, vals, name):
+        a0 = vals[0].act
+        ctot = sum(v.act.C for v in vals)
+        cat = self._act(name, a0.N, a0.H, a0.W, ctot)
+        hs = [v.act.H for v in vals] + [0] * (4 - len(vals))
+        ws = [v.act.W for v in vals] + [0] * (4 - len(vals))
+        cs = [v.act.C for v in vals] + [0] * (4 - len(vals))
+        self.fwd.add(C.OP_BILINEAR_CAT, ints=[self.dtid, len(vals), a0.N, a0.H, a0.W] + hs + ws + cs,
+                     ptrs=[C.ptr(cat.t)] + [C.ptr(v.act.t) for v in vals])
+        for v in vals:
+            assert v.bn is None and not v.relu
+            v.act.nuse += 1
+        self.tape.append(('cat', list(vals), cat))
+        return Val(cat)
+
+    # ---- network walk (reference: PoseHighResolutionNet.forward, pose_hrnet.py:511-568) ----
+    def _build(self):
+        net = self.net
+        N, H, W = self.N, self.H, self.W
+        cv, bn = net.convs, net.bns
+        if not self.training:
+            for b in net.bn_list:
+                m = b.mod
+                self.fwd.add(C.OP_BN_FINALIZE, ints=(0, b.C, 0), floats=(1.0, 0.1, m.eps),
+                             ptrs=(None, C.ptr(m.weight), C.ptr(m.bias), C.ptr(m.running_mean),
+                                   C.ptr(m.running_var), None, C.ptr(b.scale), C.ptr(b.shift), None, None))
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        cols = self._act('stem.cols', N, Ho, Wo, 32, grad=False)
+        self.in_op = self.fwd.add(C.OP_IM2COL_STEM, ints=(self.dtid, N, 3, H, W, Ho, Wo, 32),
+                                  ptrs=(None, C.ptr(cols.t)))
+        v = self.conv(Val(cols), cv['conv1'], 1, bn['bn1'], relu=True)
+        v = self.conv(v, cv['conv2'], 2, bn['bn2'], relu=True)
+        for k in range(4):
+            p = 'layer1.{}'.format(k)
+            a = self.conv(v, cv[p + '.conv1'], 1, bn[p + '.bn1'], relu=True)
+            b = self.conv(a, cv[p + '.conv2'], 1, bn[p + '.bn2'], relu=True)
+            c = self.conv(b, cv[p + '.conv3'], 1, bn[p + '.bn3'], relu=False)
+            if (p + '.downsample.0') in cv:
+                res = self.conv(v, cv[p + '.downsample.0'], 1, bn[p + '.downsample.1'], relu=False)
+            else:
+                res = v
+            v = self.sum([c, res], [0, 0], True, p + '.out')
+        ys = [v]
+        inter = None
+        for s in (2, 3, 4):
+            sc = net.stage_cfg[s]
+            nbr = sc['NUM_BRANCHES']
+            tp = 'transition{}'.format(s - 1)
+            xs = []
+            for i in range(nbr):
+                if i < len(ys):
+                    key = '{}.{}.0'.format(tp, i)
+                    xs.append(self.conv(ys[i], cv[key], 1, bn['{}.{}.1'.format(tp, i)], relu=True)
+                              if key in cv else ys[i])
+                else:
+                    t = ys[-1]
+                    for j in range(i + 1 - len(ys)):
+                        q = '{}.{}.{}'.format(tp, i, j)
+                        t = self.conv(t, cv[q + '.0'], 2, bn[q + '.1'], relu=True)
+                    xs.append(t)
+            for m in range(sc['NUM_MODULES']):
+                xs = self._hr_module(xs, 'stage{}.{}'.format(s, m), sc['NUM_BLOCKS'])
+            ys = xs
+            if s == 3:
+                inter = ys[0]
+        cat = self.bilinear_cat(ys, 'head.cat')
+        h = self.conv(cat, cv['last_layer.0'], 1, bn['last_layer.1'], relu=True)
+        out = self.conv(h, cv['last_layer.3'], 1, None, relu=False)
+        self.out_act, self.inter_act = out.act, inter.act
+        self.nj = cv['last_layer.3'].Cout
+        self.out_op = self.fwd.add(C.OP_NHWC_TO_NCHW, ints=(self.dtid, N, out.act.H, out.act.W, out.act.C, self.nj),
+                                   ptrs=(C.ptr(out.act.t), None))
+        self.inter_op = self.fwd.add(C.OP_NHWC_TO_NCHW,
+                                     ints=(self.dtid, N, inter.act.H, inter.act.W, inter.act.C, inter.act.C),
+                                     ptrs=(C.ptr(inter.act.t), None))
+        if self.need_grad:
+            self._build_backward()
+        self._resolve_scratch()
+        self.fwd.finalize()
+        self.bwd.finalize()
+
+    def _hr_module(self, xs, pre, num_blocks):
+        """HighResolutionModule.forward, pose_hrnet.py:247-266."""
+        cv, bn = self.net.convs, self.net.bns
+        nb = len(xs)
+        xs = list(xs)
+        for i in range(nb):
+            for k in range(num_blocks[i]):
+                b = '{}.branches.{}.{}'.format(pre, i, k)
+                a = self.conv(xs[i], cv[b + '.conv1'], 1, bn[b + '.bn1'], relu=True)
+                c = self.conv(a, cv[b + '.conv2'], 1, bn[b + '.bn2'], relu=False)
+                xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
+        outs = []
+        for i in range(nb):
+            terms, shifts = [], []
+            for j in range(nb):
+                if j == i:
+                    terms.append(xs[j]); shifts.append(0)
+                elif j > i:
+                    f = '{}.fuse_layers.{}.{}'.format(pre, i, j)
+                    terms.append(self.conv(xs[j], cv[f + '.0'], 1, bn[f + '.1'], relu=False))
+                    shifts.append(j - i)
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        f = '{}.fuse_layers.{}.{}.{}'.format(pre, i, j, k)
+                        t = self.conv(t, cv[f + '.0'], 2, bn[f + '.1'], relu=(k != i - j - 1))
+                    terms.append(t); shifts.append(0)
+            # the output-resolution term first (sum_terms sizes the output from term 0)
+            order = sorted(range(nb), key=lambda q: shifts[q])
+            outs.append(self.sum([terms[q] for q in order], [shifts[q] for q in order], True,
+                                 '{}.fuse.{}'.format(pre, i)))
+        return outs
+
+    # ---- backward recording ---------------------------------------------------------------
+    def _bn_backward(self, y, g_src, mask, sh, inner_relu):
+        """BatchNorm backward for raw act y: reads the upstream gradient from g_src (pooled over
+        2^sh blocks, masked by mask>0 and the BN's own ReLU), writes d(raw) into y.g."""
+        b = y.bn
+        blocks = C.call('hrnet_reduce_blocks', y.N, y.H, y.W, y.C)
+        self.max_bwd_part = max(self.max_bwd_part, blocks * 2 * y.C)
+        m = b.mod
+        i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
+                         ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
+        self._scratch(self.bwd, i, 0, 'bwdpart')
+        j = self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
+                         ptrs=(None, C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                               C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
+        self._scratch(self.bwd, j, 0, 'bwdpart')
+        self.bwd.add(C.OP_GRAD_TERM, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0, 0),
+                     ptrs=(C.ptr(y.g), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.coef)))
+        y.bn_done = True
+        y.ginit = True
+
+    def _build_backward(self):
+        net = self.net
+        # d(heatmaps) NCHW f32 -> NHWC grad of the final conv; d(inter_feat) likewise (optional)
+        oa = self.out_act
+        self.gout_op = self.bwd.add(C.OP_NCHW_TO_NHWC, ints=(self.dtid, oa.N, oa.H, oa.W, oa.C, self.nj),
+                                    ptrs=(None, C.ptr(oa.g)))
+        oa.ginit = True
+        relu_of = {}   # act -> relu flag its consumers apply (uniform per act in this network)
+        for e in self.tape:
+            if e[0] == 'conv':
+                relu_of[id(e[1].act)] = e[1].relu
+            elif e[0] == 'sum':
+                for t in e[1]:
+                    relu_of[id(t.act)] = t.relu
+        self.inter_gop = None
+        for e in reversed(self.tape):
+            if e[0] == 'cat':
+                _, vals, cat = e
+                hs = [v.act.H for v in vals] + [0] * (4 - len(vals))
+                ws = [v.act.W for v in vals] + [0] * (4 - len(vals))
+                cs = [v.act.C for v in vals] + [0] * (4 - len(vals))
+                assert not any(v.act.ginit for v in vals)
+                self.bwd.add(C.OP_BILINEAR_CAT_BWD,
+                             ints=[self.dtid, len(vals), cat.N, cat.H, cat.W] + hs + ws + cs + [0],
+                             ptrs=[C.ptr(cat.g)] + [C.ptr(v.act.g) for v in vals])
+                for v in vals:
+                    v.act.ginit = True
+            elif e[0] == 'sum':
+                _, terms, shifts, relu_out, out = e
+                if out is self.inter_act and self.inter_gop is None:
+                    # optional external gradient of inter_feat: slot patched at run time
+                    self.inter_gop = len(self.bwd)
+                if not out.ginit:
+                    # no consumer produced a gradient (cannot happen for this network)
+                    raise RuntimeError('no gradient reaches ' + out.name)
+                mask = C.ptr(out.t) if relu_out else None
+                for t, sh in zip(terms, shifts):
+                    a = t.act
+                    if a.bn is not None and a.nuse == 1 and self.training:
+                        # single consumer: fuse pooling + masks + BatchNorm backward
+                        self._bn_backward(a, C.ptr(out.g), mask, sh, t.relu)
+                    else:
+                        # accumulate d(post-activation value); BN backward runs at the producer
+                        assert sh == 0
+                        self.bwd.add(C.OP_GRAD_TERM,
+                                     ints=(self.dtid, a.N, a.H, a.W, a.C, 0, 0, 1 if a.ginit else 0),
+                                     ptrs=(C.ptr(a.g), C.ptr(out.g), mask, None, None, None, None))
+                        a.ginit = True
+            elif e[0] == 'conv':
+                _, xin, crec, stride, y, bnrec = e
+                x = xin.act
+                ks = 1 if crec.stem else crec.ks
+                if not y.ginit:
+                    raise RuntimeError('no gradient reaches ' + y.name)
+                if bnrec is not None and not y.bn_done:
+                    # y.g holds d(post-activation) summed over consumers -> d(raw), in place
+                    self._bn_backward(y, C.ptr(y.g), None, 0, relu_of.get(id(y), False))
+                w = crec.mod.weight
+                if crec.mod.bias is not None:
+                    blocks = C.call('hrnet_reduce_blocks', 1, 1, y.pixels, y.C)
+                    self.max_bwd_part = max(self.max_bwd_part, blocks * y.C)
+                    i = self.bwd.add(C.OP_BIAS_GRAD, ints=(self.dtid, y.pixels, y.C, crec.Cout, 1),
+                                     ptrs=(C.ptr(y.g), C.ptr(net.grad_of(crec.mod.bias)), None))
+                    self._scratch(self.bwd, i, 2, 'bwdpart')
+                nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
+                self.max_slab = max(self.max_slab, nsplit * y.C * ks * ks * x.C)
+                i = self.bwd.add(C.OP_WGRAD,
+                                 ints=(self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride,
+                                       1 if xin.relu else 0, nsplit),
+                                 ptrs=(C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
+                                       C.ptr(xin.bn.shift) if xin.bn else None, None))
+                self._scratch(self.bwd, i, 4, 'slab')
+                i = self.bwd.add(C.OP_WGRAD_REDUCE,
+                                 ints=(nsplit, y.C, x.C, ks, crec.Cout, crec.Cin, 1 if crec.stem else 0, 1),
+                                 ptrs=(None, C.ptr(net.grad_of(w))))
+                self._scratch(self.bwd, i, 0, 'slab')
+                if crec.stem:
+                    self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
+                if x.g is not None:
+                    # input gradient = conv of dY with the transposed kernel (zero-stuffed for stride 2)
+                    self.bwd.add(C.OP_CONV,
+                                 ints=(self.dtid, y.N, y.H, y.W, y.C, x.H, x.W, x.C, ks, stride,
+                                       1 if stride == 2 else 0, 0, 1 if x.ginit else 0),
+                                 ptrs=(C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None))
+                    x.ginit = True
+                self.bucket_marks.append((len(self.bwd), crec.prefix))
+
+    def _resolve_scratch(self):
+        stats = self._f32(max(self.max_stats, 1))
+        slab = self._f32(max(self.max_slab, 1))
+        part = self._f32(max(self.max_bwd_part, 1))
+        table = {'stats': stats, 'slab': slab, 'bwdpart': part}
+        for prog, idx, slot, kind in self.pending:
+            prog.ops[idx].p[slot] = C.ptr(table[kind])
+        self.pending = []
+
+    # ---- execution --------------------------------------------------------------------------
+    def run_forward(self, x):
+        N = self.N
+        oa, ia = self.out_act, self.inter_act
+        hm = torch.empty((N, self.nj, oa.H, oa.W), dtype=torch.float32, device=self.dev)
+        inter = torch.empty((N, ia.C, ia.H, ia.W), dtype=torch.float32, device=self.dev)
+        self.fwd.set_ptr(self.in_op, 0, x.data_ptr())
+        self.fwd.set_ptr(self.out_op, 1, hm.data_ptr())
+        self.fwd.set_ptr(self.inter_op, 1, inter.data_ptr())
+        self.fwd.run()
+        return hm, inter
+
+    def run_backward(self, g_hm, g_inter=None, segment_hook=None):
+        self.bwd.set_ptr(self.gout_op, 0, g_hm.data_ptr())
+        if g_inter is not None:
+            # d(inter_feat) joins the gradient of stage3's branch-0 output before its consumers'
+            # contributions are read: run up to that op, add it, continue
+            cut = self.inter_gop
+            self.bwd.run(0, cut)
+            ia = self.inter_act
+            tmp = torch.empty(ia.N * ia.H * ia.W * ia.C * self.esize, dtype=torch.uint8, device=self.dev)
+            C.call('hrnet_nchw_to_nhwc', self.dtid, g_inter.data_ptr(), tmp.data_ptr(), ia.N, ia.H, ia.W, ia.C,
+                   ia.C, C.stream_ptr())
+            C.call('hrnet_grad_term', self.dtid, ia.g.data_ptr(), tmp.data_ptr(), None, None, None, None, None,
+                   ia.N, ia.H, ia.W, ia.C, 0, 0, 1, C.stream_ptr())
+            self._run_segments(cut, len(self.bwd), segment_hook)
+        else:
+            self._run_segments(0, len(self.bwd), segment_hook)
+
+    def _run_segments(self, lo, hi, hook):
+        if hook is None:
+            self.bwd.run(lo, hi)
+            return
+        cuts = [c for c in hook.cuts if lo < c < hi]
+        prev = lo
+        for c in cuts:
+            self.bwd.run(prev, c)
+            hook.after(c)
+            prev = c
+        self.bwd.run(prev, hi)
+        hook.after(hi)

@@ -1,0 +1,142 @@
+"""Device-side state of one PoseHighResolutionNet: flat f32 master parameters / gradients,
+packed (f32 or bf16) kernel weights, BatchNorm coefficient buffers and the cached plans."""
+import torch
+import torch.nn as nn
+
+from . import _capi as C
+from .engine import BNRec, ConvRec, Plan, Program
+
+
+class HipNet(object):
+    def __init__(self, module, stage_cfg, compute_dtype):
+        self.module = module
+        self.stage_cfg = stage_cfg          # {2: STAGE2 cfg, 3: ..., 4: ...}
+        self.compute_dtype = compute_dtype
+        self.dtid = C.dtype_id(compute_dtype)
+        C.lib()                              # fail loudly now if the HIP library is missing
+        params = list(module.parameters())
+        if not params or not params[0].is_cuda:
+            raise RuntimeError('pose_hrnet: parameters must live on a HIP device (model.cuda()); '
+                               'there is no CPU path')
+        self.device = params[0].device
+        self.plans = {}
+        self.fwd_packed = self.bwd_packed = False
+        self._flatten(params)
+        self._records()
+
+    # ---- flat master parameters / gradients --------------------------------------------------
+    def _flatten(self, params):
+        total = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.params = params
+        self._gview = {}
+        self.offsets = {}
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                self._gview[id(p)] = self.flat_g[off:off + n].view(p.shape)
+                self.offsets[id(p)] = (off, n)
+                if p.grad is not None:
+                    self._gview[id(p)].copy_(p.grad)
+                    p.grad = self._gview[id(p)]
+                off += n
+        self.total_params = total
+
+    def grad_of(self, p):
+        return self._gview[id(p)]
+
+    def _records(self):
+        self.convs, self.bns, self.bn_list, self.bias_pad = {}, {}, {}, {}
+        self.bn_list = []
+        for name, m in self.module.named_modules():
+            if isinstance(m, nn.Conv2d):
+                r = ConvRec(name, m, stem=(name == 'conv1'))
+                es = torch.empty((), dtype=self.compute_dtype).element_size()
+                taps = r.ks * r.ks
+                nf = r.Cout_pad * (1 if r.stem else taps) * r.Cin_pad
+                r.wf = torch.empty(nf * es, dtype=torch.uint8, device=self.device)
+                if not r.stem:
+                    r.wd = torch.empty(r.Cin_pad * taps * r.Cout_pad * es, dtype=torch.uint8, device=self.device)
+                self.convs[name] = r
+                if m.bias is not None:
+                    self.bias_pad[name] = torch.zeros(r.Cout_pad, dtype=torch.float32, device=self.device)
+            elif isinstance(m, nn.BatchNorm2d):
+                b = BNRec(name, m, self.device)
+                self.bns[name] = b
+                self.bn_list.append(b)
+        self.pack_f, self.pack_d = Program(), Program()
+        for r in self.convs.values():
+            w = r.mod.weight
+            self.pack_f.add(C.OP_PACK_WEIGHTS,
+                            ints=(self.dtid, r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, 2 if r.stem else 0),
+                            ptrs=(C.ptr(w), C.ptr(r.wf)))
+            if r.wd is not None:
+                self.pack_d.add(C.OP_PACK_WEIGHTS,
+                                ints=(self.dtid, r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, 1),
+                                ptrs=(C.ptr(w), C.ptr(r.wd)))
+        self.pack_f.finalize()
+        self.pack_d.finalize()
+
+    def pack_weights(self, for_backward):
+        """master f32 OIHW -> kernel layouts (forward always, transposed dgrad copy on demand)"""
+        if not self.fwd_packed:
+            self.pack_f.run()
+            for name, buf in self.bias_pad.items():
+                b = self.convs[name].mod.bias
+                buf[:b.numel()].copy_(b.detach())
+            self.fwd_packed = True
+        if for_backward and not self.bwd_packed:
+            self.pack_d.run()
+            self.bwd_packed = True
+
+    def mark_weights_dirty(self):
+        self.fwd_packed = self.bwd_packed = False
+
+    # ---- forward / backward -------------------------------------------------------------------
+    def plan(self, N, H, W, training, need_grad):
+        key = (N, H, W, bool(training), bool(need_grad))
+        p = self.plans.get(key)
+        if p is None:
+            p = Plan(self, N, H, W, training, need_grad)
+            self.plans[key] = p
+        return p
+
+    def forward(self, x, training, need_grad):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('pose_hrnet expects (B,3,H,W) input, got {}'.format(tuple(x.shape)))
+        N, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('pose_hrnet: input height/width must be multiples of 32, got {}x{}'.format(H, W))
+        if need_grad and not training:
+            raise RuntimeError('pose_hrnet: backward through eval-mode BatchNorm is not implemented')
+        self.pack_weights(for_backward=need_grad)
+        plan = self.plan(N, H, W, training, need_grad)
+        hm, inter = plan.run_forward(x)
+        return hm, inter, plan
+
+    def prepare_grads(self):
+        """PyTorch semantics for .grad: None -> fresh, ours -> accumulate."""
+        none = [p.grad is None for p in self.params]
+        if all(none):
+            self.flat_g.zero_()
+            for p in self.params:
+                p.grad = self._gview[id(p)]
+            return
+        for p in self.params:
+            if p.grad is None:
+                self._gview[id(p)].zero_()
+                p.grad = self._gview[id(p)]
+            elif p.grad.data_ptr() != self._gview[id(p)].data_ptr():
+                self._gview[id(p)].copy_(p.grad)
+                p.grad = self._gview[id(p)]
+
+    def backward(self, plan, g_hm, g_inter, segment_hook=None):
+        self.prepare_grads()
+        if segment_hook is not None:
+            segment_hook.begin(plan)
+        plan.run_backward(g_hm, g_inter, segment_hook)
+        self.mark_weights_dirty()   # an optimizer step normally follows

@@ -1,0 +1,121 @@
+"""Optimizer + data-parallel gradient exchange over the flat parameter/gradient buffers.
+
+FlatAdam   torch.optim.Adam semantics (lib/utils/utils.py:81-85: lr, L2 weight decay added to the
+           gradient; betas (0.9, 0.999), eps 1e-8) as ONE fused HIP kernel over the flat f32 master
+           parameters instead of 921 per-tensor updates.
+GradSync   replaces DistributedDataParallel's reducer (tools/train.py:239-244): sum-all-reduce of
+           the flat gradient over RCCL, issued bucket by bucket while the backward program is
+           still running (gradients complete in reverse layer order = descending flat offsets),
+           the 1/world_size average folded into the optimizer's gradient scale.
+"""
+import torch
+
+from . import _capi as C
+
+
+class FlatAdam(object):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.grad_scale = 1.0
+        self._state_for = None
+        self.param_groups = [{'lr': lr, 'initial_lr': lr, 'weight_decay': weight_decay, 'betas': betas, 'eps': eps}]
+
+    def _state(self):
+        net = self.model.hip()
+        if self._state_for is not net:
+            self.exp_avg = torch.zeros_like(net.flat_p)
+            self.exp_avg_sq = torch.zeros_like(net.flat_p)
+            self._state_for = net
+        return net
+
+    def zero_grad(self, set_to_none=True):
+        net = self._state()
+        if set_to_none:
+            for p in net.params:
+                p.grad = None
+        else:
+            net.flat_g.zero_()
+
+    def step(self):
+        net = self._state()
+        self.step_count += 1
+        lr = self.param_groups[0]['lr']
+        C.call('hrnet_adam_step', net.flat_p.data_ptr(), net.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+               self.exp_avg_sq.data_ptr(), net.total_params, lr, self.betas[0], self.betas[1], self.eps,
+               self.weight_decay, self.step_count, self.grad_scale, C.stream_ptr())
+        net.mark_weights_dirty()
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'param_groups': self.param_groups}
+
+    def load_state_dict(self, sd):
+        self._state()
+        self.step_count = sd['step']
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.param_groups = sd['param_groups']
+
+
+class GradSync(object):
+    """Bucketed all-reduce of the flat gradient, overlapped with the backward program.
+
+    Installed as `model._segment_hook`; engine.Plan._run_segments calls `after(op_index)` right
+    after enqueueing a backward segment."""
+
+    def __init__(self, model, bucket_bytes=32 << 20, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.model = model
+        self.bucket_bytes = bucket_bytes
+        self.cuts = []
+        self._ranges = {}
+        self._works = []
+        self._plan = None
+        model._segment_hook = self
+
+    def _prepare(self, plan):
+        net = plan.net
+        total = net.total_params
+        self.cuts, self._ranges = [], {}
+        hi = total
+        pending = 0
+        last = total
+        for op_index, prefix in plan.bucket_marks:
+            w = net.convs[prefix].mod.weight
+            off = net.offsets[id(w)][0]
+            if off > last:        # not monotone: fall back to one exchange at the end
+                self.cuts, self._ranges = [], {}
+                break
+            pending = hi - off
+            last = off
+            if pending * 4 >= self.bucket_bytes:
+                self.cuts.append(op_index)
+                self._ranges[op_index] = (off, hi)
+                hi = off
+        self._tail = (0, hi)
+        self._end = len(plan.bwd)
+        self._plan = plan
+
+    def begin(self, plan):
+        if self._plan is not plan:
+            self._prepare(plan)
+        self._works = []
+
+    def after(self, op_index):
+        net = self._plan.net
+        rng = self._ranges.get(op_index)
+        if rng is None and op_index == self._end:
+            rng = self._tail
+        if rng is None or rng[1] <= rng[0]:
+            return
+        self._works.append(self.dist.all_reduce(net.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works = []

@@ -1,0 +1,245 @@
+/*
+ * hrnet_hip.h — C ABI of libhrnet_hip.so: the MI355X (gfx950) device path of the HRNet
+ * hand-pose hot path.
+ *
+ * The reference has no FFI on this path: every op below replaces a stock PyTorch op
+ * reached from /root/reference/lib/models/pose_hrnet.py, lib/core/loss.py and
+ * lib/utils/heatmap_decoding.py (file:line cited per entry point).  The host side
+ * (hrnet-hand-pose-estimation_amd/lib/hipnet/) binds these with ctypes; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator); the library allocates nothing.
+ *   - activations are NHWC; `dtype` selects the storage/arithmetic type of activations and
+ *     packed weights: HR_F32 (exact f32 MFMA, f32 accumulate) or HR_BF16 (bf16 MFMA, f32
+ *     accumulate). Statistics, BN coefficients, partial sums, losses and master weights
+ *     are always f32.
+ *   - stream-ordered and re-entrant: kernels are enqueued on `stream`, nothing synchronises.
+ *   - return 0 on success, a negative HR_E_* code otherwise; hrnet_last_error_string()
+ *     describes the last failure of the calling thread. Nothing throws across the ABI.
+ */
+#ifndef HRNET_HIP_H
+#define HRNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hr_stream_t; /* hipStream_t */
+
+enum { HR_F32 = 0, HR_BF16 = 1 };
+
+enum {
+  HR_OK = 0,
+  HR_E_BADARG = -1,   /* shape / alignment / dtype the kernels do not support */
+  HR_E_LAUNCH = -2,   /* HIP reported a launch error */
+  HR_E_BADOP = -3     /* unknown op kind in a program */
+};
+
+/* ---- op kinds of a recorded program (hrnet_program_run) -------------------------------- */
+enum {
+  HR_OP_CONV = 1,          /* conv / dgrad (implicit GEMM, MFMA) */
+  HR_OP_WGRAD = 2,         /* weight gradient partial slabs */
+  HR_OP_WGRAD_REDUCE = 3,  /* slabs -> OIHW f32 gradient */
+  HR_OP_BN_FINALIZE = 4,   /* stat partials -> scale/shift (+ running stats) */
+  HR_OP_SUM_TERMS = 5,     /* out = relu(sum_t relu_t(affine_t(up_t(src_t)))) */
+  HR_OP_GRAD_TERM = 6,     /* dst (+)= A*pool(g*mask) + B*y + C */
+  HR_OP_BN_BWD_REDUCE = 7, /* per-channel sum(dz), sum(dz*y) partials */
+  HR_OP_BN_BWD_FINALIZE = 8,
+  HR_OP_BILINEAR_CAT = 9,
+  HR_OP_BILINEAR_CAT_BWD = 10,
+  HR_OP_IM2COL_STEM = 11,
+  HR_OP_NHWC_TO_NCHW = 12,
+  HR_OP_NCHW_TO_NHWC = 13,
+  HR_OP_PACK_WEIGHTS = 14,
+  HR_OP_BIAS_GRAD = 15,
+  HR_OP_FILL = 16
+};
+
+/* One recorded op: integer / float / pointer slots, meaning per kind (see the
+ * hrnet_* function of the same name; slots are filled in argument order). */
+typedef struct HrOp {
+  int32_t kind;
+  int32_t i[19];
+  float f[4];
+  void* p[14];
+} HrOp;
+
+const char* hrnet_last_error_string(void);
+int hrnet_abi_version(void);
+
+/* Run `n` recorded ops in order on `stream` (one host call per forward / backward pass). */
+int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream);
+
+/*
+ * Convolution as implicit GEMM on MFMA. Replaces nn.Conv2d forward (pose_hrnet.py:22-25,
+ * :65-71, :200-204, :218-222, :283-287, :334-347) and, with packed transposed weights, its
+ * input gradient.
+ *   x        [N,H,W,Cin]   (Cin % 8 == 0; HR_F32: % 4)
+ *   w        packed [Cout][ks*ks][Cin] in `dtype` (hrnet_pack_weights)
+ *   in_scale/in_shift  optional per-Cin affine applied to x on load (the producer's
+ *            BatchNorm, pose_hrnet.py:45,49 ...), then ReLU if in_relu; zero padding is
+ *            applied AFTER the transform, as the reference pads the activated tensor.
+ *   bias     optional [Cout] f32
+ *   y        [N,Ho,Wo,Cout] (Cout % 16 == 0), overwritten or accumulated into
+ *   stats    optional [tiles][2][Cout] f32 per-tile sum / sum of squares of y (BatchNorm
+ *            batch statistics, finished by hrnet_bn_finalize); tiles = hrnet_conv_tiles()
+ *   ks 1|3, pad = ks/2, stride 1|2.  upz=1: x is read as if zero-stuffed x2 (input gradient
+ *   of a stride-2 conv: logical input [N,Ho,Wo,Cin], stride forced to 1).
+ */
+int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
+                 const float* in_shift, const float* bias, void* y, float* stats, int N, int H,
+                 int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int upz,
+                 int in_relu, int accumulate, hr_stream_t stream);
+/* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
+int hrnet_conv_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, int upz, char* buf,
+                           int buflen);
+int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
+/* number of per-tile stat rows hrnet_conv2d writes for this shape */
+int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
+
+/*
+ * Weight gradient: slabs[s][Cout][ks*ks][Cin] f32 partial sums over disjoint pixel ranges
+ * (deterministic, no atomics); x is transformed on load exactly as in hrnet_conv2d.
+ *   dy [N,Ho,Wo,Cout], x [N,H,W,Cin]; nsplit slabs = hrnet_wgrad_splits().
+ */
+int hrnet_conv2d_wgrad(int dtype, const void* x, const void* dy, const float* in_scale,
+                       const float* in_shift, float* slabs, int N, int H, int W, int Cin, int Ho,
+                       int Wo, int Cout, int ks, int stride, int in_relu, int nsplit,
+                       hr_stream_t stream);
+int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
+/* slabs -> grad_oihw[Cout_real][Cin_real][ks][ks] f32 (+= if accumulate). Cout/Cin are the
+ * padded slab extents; stem: kflat=1 means slab K index is the flattened (tap,ci) of the
+ * im2col'ed stem (Cin_real*ks*ks real entries). */
+int hrnet_wgrad_reduce(const float* slabs, float* grad_oihw, int nsplit, int Cout, int Cin,
+                       int ks, int Cout_real, int Cin_real, int kflat, int accumulate,
+                       hr_stream_t stream);
+
+/*
+ * Pack f32 OIHW master weights into the kernels' layout.
+ *   mode 0: forward  [Cout_pad][ks*ks][Cin_pad]
+ *   mode 1: dgrad    [Cin_pad][ks*ks flipped][Cout_pad]  (transposed conv)
+ *   mode 2: stem     [Cout_pad][Cin_pad] with k = (r*ks+s)*Cin_real + ci  (im2col order)
+ */
+int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, int Cout, int Cin, int ks,
+                       int Cout_pad, int Cin_pad, int mode, hr_stream_t stream);
+
+/*
+ * BatchNorm2d statistics -> per-channel affine (nn.BatchNorm2d in pose_hrnet.py:34,37,66-73,
+ * :205,:223,:285-288,:340; momentum 0.1, eps 1e-5).
+ *   training=1: mean/var from `stats` ([tiles][2][C], `count` elements per channel);
+ *               running_mean/var updated in place (unbiased var), num_batches_tracked += 1
+ *   training=0: scale/shift from the running statistics.
+ *   scale = gamma*invstd, shift = beta - mean*scale; save_mean/save_invstd kept for backward.
+ */
+int hrnet_bn_finalize(const float* stats, int tiles, int C, float count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps, int training,
+                      float* scale, float* shift, float* save_mean, float* save_invstd,
+                      hr_stream_t stream);
+
+/*
+ * out[N,Ho,Wo,C] = relu_out( sum_{t<nterms} relu_t( src_t[nearest-up by 2^sh_t] * scale_t + shift_t ) )
+ * Residual adds (pose_hrnet.py:54-55, :95-96) and fuse-layer sums with nearest upsampling
+ * (pose_hrnet.py:257-264, :206). scale_t may be NULL (identity term).
+ */
+int hrnet_sum_terms(int dtype, void* out, int N, int Ho, int Wo, int C, int nterms,
+                    const void* const* src, const float* const* scale, const float* const* shift,
+                    const int* shifts, const int* relus, int relu_out, hr_stream_t stream);
+
+/*
+ * Backward of one term of hrnet_sum_terms / of a BN(+ReLU) that feeds a conv:
+ *   dz[q,c]  = sum_{p in 2^sh x 2^sh block of q} g[p,c] * [mask_out[p,c] > 0] * [scale*y+shift > 0 if inner_relu]
+ *   dst[q,c] (+)= A[c]*dz + B[c]*y[q,c] + C[c]          (coef = [3][C] from hrnet_bn_bwd_finalize;
+ *                                                        coef NULL: dst (+)= dz)
+ * g, mask_out: [N,H<<sh,W<<sh,C]; y, dst: [N,H,W,C].
+ */
+int hrnet_grad_term(int dtype, void* dst, const void* g, const void* mask_out, const void* y,
+                    const float* scale, const float* shift, const float* coef, int N, int H, int W,
+                    int C, int sh, int inner_relu, int accumulate, hr_stream_t stream);
+/* partials[blocks][2][C]: sum(dz), sum(dz*y) with dz as above; blocks = hrnet_reduce_blocks() */
+int hrnet_bn_bwd_reduce(int dtype, float* partials, const void* g, const void* mask_out,
+                        const void* y, const float* scale, const float* shift, int N, int H, int W,
+                        int C, int sh, int inner_relu, hr_stream_t stream);
+int hrnet_reduce_blocks(int N, int H, int W, int C);
+/* dgamma/dbeta (+=) and coef[3][C]: A = gamma*invstd, B = -gamma*invstd^2*mean(dz*xhat)/... */
+int hrnet_bn_bwd_finalize(const float* partials, int blocks, int C, float count,
+                          const float* gamma, const float* save_mean, const float* save_invstd,
+                          float* dgamma, float* dbeta, float* coef, int accumulate,
+                          hr_stream_t stream);
+
+/*
+ * Head input: cat[N,H,W,sum(C_j)] = [x0, bilinear(x1), bilinear(x2), bilinear(x3)]
+ * (F.upsample(mode='bilinear'), align_corners=False, then torch.cat: pose_hrnet.py:560-565).
+ * Branch j has spatial size (H>>j, W>>j) ... given explicitly. nbr <= 4.
+ */
+int hrnet_bilinear_cat(int dtype, void* cat, const void* const* xs, const int* hs, const int* ws,
+                       const int* cs, int nbr, int N, int H, int W, hr_stream_t stream);
+/* dxs[j] (+)= bilinear^T(dcat[..., slice_j]) (gather form, deterministic) */
+int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const int* hs,
+                           const int* ws, const int* cs, int nbr, int N, int H, int W,
+                           int accumulate, hr_stream_t stream);
+
+/* stem: NCHW f32 image -> im2col rows [N,Ho,Wo,Kpad] (k = (r*3+s)*C + c), 3x3 stride 2 pad 1
+ * (conv1, pose_hrnet.py:283-284,512). */
+int hrnet_im2col_stem(int dtype, const float* img_nchw, void* cols, int N, int C, int H, int W,
+                      int Ho, int Wo, int Kpad, hr_stream_t stream);
+/* [N,H,W,Cp] dtype -> [N,C,H,W] f32 (first C channels), and back (pad channels zeroed). */
+int hrnet_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int H, int W, int Cp, int C,
+                       hr_stream_t stream);
+int hrnet_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int H, int W, int Cp, int C,
+                       hr_stream_t stream);
+/* dbias[c] (+)= sum over pixels of dy[pixels, Cp] for c < C (conv bias, pose_hrnet.py:334-347);
+ * scratch: hrnet_reduce_blocks(1,1,pixels,Cp) * Cp floats */
+int hrnet_bias_grad(int dtype, const void* dy, float* dbias, float* scratch, int pixels, int Cp,
+                    int C, int accumulate, hr_stream_t stream);
+int hrnet_fill_zero(void* p, int64_t bytes, hr_stream_t stream);
+
+/*
+ * HeatmapLoss (lib/core/loss.py:19-28): loss = mean_{b,k} sum_{h,w} (pred-gt)^2 (mode 0)
+ * or |pred-gt| (mode 1). pred/gt are NCHW f32 [B,K,H,W] (the module contract).
+ * partial: [B*K] f32 scratch; loss: [1] f32.
+ */
+int hrnet_heatmap_loss_fwd(const float* pred, const float* gt, float* partial, float* loss, int BK,
+                           int HW, int mode, hr_stream_t stream);
+/* dpred = gout * d loss / d pred */
+int hrnet_heatmap_loss_bwd(const float* pred, const float* gt, const float* gout, float* dpred,
+                           int BK, int HW, int mode, hr_stream_t stream);
+
+/*
+ * get_final_preds (lib/utils/heatmap_decoding.py:87-107), hms NCHW f32 [B,K,H,W] -> preds [B,K,2].
+ *   expectation (use_softmax=True): (sum x*h, sum y*h), pixel coordinates, no normalisation
+ *   argmax (use_softmax=False): first maximal flat index; u = idx % H, v = idx / H (H as the
+ *   reference uses shape[2] for both)
+ * maxvals (optional, [B,K]) receives the maximum (get_max_preds, lib/core/inference.py:18-46,
+ * which uses W for % and / and zeroes preds whose max <= 0: flag `inference_style`).
+ */
+int hrnet_decode_expectation(const float* hms, float* preds, int BK, int H, int W,
+                             hr_stream_t stream);
+int hrnet_decode_expectation_bwd(const float* gpreds, float* dhms, int BK, int H, int W,
+                                 int accumulate, hr_stream_t stream);
+int hrnet_decode_argmax(const float* hms, float* preds, float* maxvals, int BK, int H, int W,
+                        int inference_style, hr_stream_t stream);
+
+/*
+ * JointsMSELoss (lib/core/loss.py:37-50): sum_bk ||pred-gt||_2 * vis / max(1, sum vis), or
+ * sum/K without visibility (vis NULL). pred/gt [B,K,2] f32, vis [B,K] f32.
+ */
+int hrnet_joints_loss_fwd(const float* pred, const float* gt, const float* vis, float* loss, int B,
+                          int K, hr_stream_t stream);
+int hrnet_joints_loss_bwd(const float* pred, const float* gt, const float* vis, const float* gout,
+                          float* dpred, int B, int K, hr_stream_t stream);
+
+/* Adam step over a flat f32 parameter buffer (torch.optim.Adam semantics incl. L2 weight
+ * decay added to the gradient; lib/utils/utils.py:81-85, lib/core/function.py:101-106). */
+int hrnet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, hr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRNET_HIP_H */

@@ -1,0 +1,431 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against plain torch
+fp32 on the CPU. fp32 device path: <= 1e-4 relative (exact f32 MFMA, only summation order
+differs); bf16 path: <= 3e-2 relative (bf16 operands, f32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _h():
+    import hip_helpers as hh
+    return hh
+
+
+def _q(t, dtype):
+    """round a CPU f32 tensor through the device dtype so both sides see identical inputs"""
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, ks, stride, affine, relu, bias
+    (2, 16, 16, 32, 32, 3, 1, True, True, False),
+    (1, 64, 64, 32, 32, 3, 1, False, False, False),
+    (2, 32, 32, 64, 64, 3, 1, True, True, False),
+    (3, 16, 16, 128, 128, 3, 1, True, False, False),
+    (2, 8, 8, 256, 256, 3, 1, True, True, False),
+    (2, 32, 32, 64, 128, 3, 2, True, True, False),
+    (2, 16, 16, 32, 32, 3, 2, False, False, False),
+    (2, 16, 16, 256, 32, 3, 1, True, True, False),
+    (2, 16, 16, 64, 256, 1, 1, True, True, False),
+    (1, 16, 16, 480, 480, 1, 1, False, False, True),
+    (2, 8, 8, 480, 32, 1, 1, True, True, True),
+    (1, 12, 9, 48, 96, 3, 1, True, True, False),     # w48-style odd sizes, Cin not /32
+    (1, 12, 20, 48, 48, 3, 2, False, True, False),
+])
+def test_conv2d_forward(dtype, case):
+    hh = _h()
+    N, H, W, Cin, Cout, ks, stride, affine, relu, use_bias = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks), dtype)
+    sc = (torch.rand(Cin, generator=g) + 0.5) if affine else None
+    sh = (torch.rand(Cin, generator=g) - 0.5) if affine else None
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    xa = x
+    if affine:
+        xa = xa * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if relu:
+        xa = F.relu(xa)
+    xa = _q(xa, dtype)   # the kernel rounds the transformed operand to the compute dtype
+    ref = F.conv2d(xa, w, bias, stride=stride, padding=ks // 2)
+    xd = hh.nhwc(x, dtype)
+    wp, cop, cip = hh.pack_weights(w, dtype)
+    y, st = hh.conv2d(xd, wp, N, H, W, Cin, cop, ks, stride, dtype,
+                      in_scale=sc.to(hh.DEV) if affine else None, in_shift=sh.to(hh.DEV) if affine else None,
+                      bias=bias.to(hh.DEV) if use_bias else None, in_relu=relu, stats=True)
+    got = hh.from_nhwc(y, Cout)
+    assert hh.rel_err(got, ref) <= TOL[dtype]
+    # BatchNorm statistics from the epilogue (f32 accumulators)
+    s = st.sum(0).cpu()
+    ref_s1 = ref.sum((0, 2, 3))
+    ref_s2 = (ref * ref).sum((0, 2, 3))
+    assert hh.rel_err(s[0, :Cout], ref_s1) <= 5 * TOL[dtype] + 1e-4
+    assert hh.rel_err(s[1, :Cout], ref_s2) <= 5 * TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [
+    (2, 16, 16, 32, 32, 3, 1),
+    (2, 32, 32, 64, 128, 3, 2),
+    (1, 16, 16, 32, 64, 3, 2),
+    (2, 16, 16, 64, 256, 1, 1),
+    (1, 9, 12, 48, 96, 3, 2),      # odd input extent
+    (2, 8, 8, 256, 256, 3, 1),
+])
+def test_conv2d_input_gradient(dtype, case):
+    """dgrad = conv of dY with the transposed/flipped packed kernel (zero-stuffed for stride 2)."""
+    hh = _h()
+    N, H, W, Cin, Cout, ks, stride = case
+    g = torch.Generator().manual_seed(7)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks), dtype)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=stride, padding=ks // 2)
+    dy = _q(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    ref = x.grad
+    Ho, Wo = y.shape[2], y.shape[3]
+    wd, _, _ = hh.pack_weights(w, dtype, mode=1)
+    dyd = hh.nhwc(dy, dtype)
+    prev = torch.randn(N, H, W, Cin, generator=g)
+    out = prev.to(dtype).to(hh.DEV)
+    dx, _ = hh.conv2d(dyd, wd, N, Ho, Wo, Cout, Cin, ks, stride, dtype, upz=(stride == 2), out=out,
+                      accumulate=True, out_hw=(H, W))
+    got = hh.from_nhwc(dx) - hh.from_nhwc(prev.to(dtype))
+    assert hh.rel_err(got, ref) <= 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [
+    (2, 16, 16, 32, 32, 3, 1, True),
+    (1, 64, 64, 32, 32, 3, 1, False),
+    (2, 32, 32, 64, 64, 3, 1, True),
+    (2, 8, 8, 256, 256, 3, 1, True),
+    (2, 32, 32, 64, 128, 3, 2, True),
+    (2, 16, 16, 32, 32, 3, 2, False),
+    (2, 16, 16, 64, 256, 1, 1, True),
+    (2, 16, 16, 480, 480, 1, 1, False),
+    (1, 12, 9, 48, 96, 3, 1, True),
+    (2, 4, 4, 128, 32, 1, 1, True),
+])
+def test_conv2d_weight_gradient(dtype, case):
+    hh = _h()
+    N, H, W, Cin, Cout, ks, stride, affine = case
+    g = torch.Generator().manual_seed(11)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    sc = (torch.rand(Cin, generator=g) + 0.5) if affine else None
+    sh = (torch.rand(Cin, generator=g) - 0.5) if affine else None
+    xa = x
+    if affine:
+        xa = _q(F.relu(xa * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), dtype)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g, requires_grad=True)
+    y = F.conv2d(xa, w, None, stride=stride, padding=ks // 2)
+    dy = _q(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    got = hh.wgrad(hh.nhwc(x, dtype), hh.nhwc(dy, dtype), N, H, W, Cin, Ho, Wo, Cout, ks, stride, dtype,
+                   in_scale=sc.to(hh.DEV) if affine else None, in_shift=sh.to(hh.DEV) if affine else None,
+                   in_relu=affine).cpu()
+    assert hh.rel_err(got, w.grad) <= 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem_im2col_conv_and_wgrad(dtype):
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W = 2, 32, 48
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g, requires_grad=True)
+    wq = _q(w.detach(), dtype)
+    ref = F.conv2d(_q(img, dtype), wq, None, stride=2, padding=1)
+    cols = torch.empty(N, H // 2, W // 2, 32, dtype=dtype, device=hh.DEV)
+    imgd = img.to(hh.DEV)
+    C.call('hrnet_im2col_stem', hh.dt_id(dtype), imgd.data_ptr(), cols.data_ptr(), N, 3, H, W, H // 2,
+           W // 2, 32, C.stream_ptr())
+    wp, _, _ = hh.pack_weights(wq, dtype, mode=2)
+    y, _ = hh.conv2d(cols, wp, N, H // 2, W // 2, 32, 64, 1, 1, dtype)
+    assert hh.rel_err(hh.from_nhwc(y), ref) <= TOL[dtype]
+    # weight gradient through the flattened-K slab
+    y2 = F.conv2d(_q(img, dtype), w, None, stride=2, padding=1)
+    dy = _q(torch.randn(y2.shape, generator=g), dtype)
+    y2.backward(dy)
+    ns = C.call('hrnet_wgrad_splits', hh.dt_id(dtype), N, H // 2, W // 2, 64, 32, 1, 1)
+    slabs = torch.zeros(ns, 64, 1, 32, dtype=torch.float32, device=hh.DEV)
+    dyd = hh.nhwc(dy, dtype)
+    C.call('hrnet_conv2d_wgrad', hh.dt_id(dtype), cols.data_ptr(), dyd.data_ptr(), None, None,
+           slabs.data_ptr(), N, H // 2, W // 2, 32, H // 2, W // 2, 64, 1, 1, 0, ns, C.stream_ptr())
+    gw = torch.zeros(64, 3, 3, 3, dtype=torch.float32, device=hh.DEV)
+    C.call('hrnet_wgrad_reduce', slabs.data_ptr(), gw.data_ptr(), ns, 64, 32, 3, 64, 3, 1, 0, C.stream_ptr())
+    assert hh.rel_err(gw.cpu(), w.grad) <= 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_finalize_train_and_eval(dtype):
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cc = 3, 16, 16, 64
+    g = torch.Generator().manual_seed(5)
+    x = _q(torch.randn(N, 32, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cc, 32, 3, 3, generator=g) * 0.1, dtype)
+    y_ref = F.conv2d(x, w, None, padding=1)
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5)
+        bn.bias.copy_(torch.rand(Cc, generator=g) - 0.5)
+        bn.running_mean.copy_(torch.rand(Cc, generator=g))
+        bn.running_var.copy_(torch.rand(Cc, generator=g) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    z_ref = bn(y_ref)
+    wp, _, _ = hh.pack_weights(w, dtype)
+    y, st = hh.conv2d(hh.nhwc(x, dtype), wp, N, H, W, 32, Cc, 3, 1, dtype, stats=True)
+    d = hh.DEV
+    gam, bet = bn.weight.detach().to(d), bn.bias.detach().to(d)
+    rm, rv = rm0.to(d), rv0.to(d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    scale, shift, mean, invstd = (torch.empty(Cc, device=d) for _ in range(4))
+    C.call('hrnet_bn_finalize', st.data_ptr(), st.shape[0], Cc, float(N * H * W), gam.data_ptr(), bet.data_ptr(),
+           rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1, 1e-5, 1, scale.data_ptr(), shift.data_ptr(),
+           mean.data_ptr(), invstd.data_ptr(), C.stream_ptr())
+    z = hh.from_nhwc(y) * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)
+    assert hh.rel_err(z, z_ref.detach()) <= 2 * TOL[dtype]
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=tol, atol=tol)
+    assert int(nbt.item()) == 1
+    # eval: scale/shift from the running statistics
+    C.call('hrnet_bn_finalize', None, 0, Cc, 1.0, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+           None, 0.1, 1e-5, 0, scale.data_ptr(), shift.data_ptr(), None, None, C.stream_ptr())
+    ref_scale = gam.cpu() / torch.sqrt(rv.cpu() + 1e-5)
+    np.testing.assert_allclose(scale.cpu().numpy(), ref_scale.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(shift.cpu().numpy(), (bet.cpu() - rm.cpu() * ref_scale).numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_sum_terms_fuse_with_nearest_upsampling(dtype):
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cc = 2, 16, 16, 32
+    g = torch.Generator().manual_seed(9)
+    a = _q(torch.randn(N, Cc, H, W, generator=g), dtype)
+    b = _q(torch.randn(N, Cc, H // 2, W // 2, generator=g), dtype)
+    c = _q(torch.randn(N, Cc, H // 4, W // 4, generator=g), dtype)
+    sb, tb = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) - 0.5
+    sc, tc = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) - 0.5
+    aff = lambda t, s, o: t * s.view(1, -1, 1, 1) + o.view(1, -1, 1, 1)
+    ref = F.relu(a + F.interpolate(aff(b, sb, tb), scale_factor=2, mode='nearest')
+                 + F.interpolate(F.relu(aff(c, sc, tc)), scale_factor=4, mode='nearest'))
+    d = hh.DEV
+    ts = [hh.nhwc(a, dtype), hh.nhwc(b, dtype), hh.nhwc(c, dtype)]
+    scs = [None, sb.to(d), sc.to(d)]
+    shs = [None, tb.to(d), tc.to(d)]
+    out = torch.empty(N, H, W, Cc, dtype=dtype, device=d)
+    C.call('hrnet_sum_terms', hh.dt_id(dtype), out.data_ptr(), N, H, W, Cc, 3, hh.ptr_array(ts), hh.ptr_array(scs),
+           hh.ptr_array(shs), hh.int_array([0, 1, 2]), hh.int_array([0, 0, 1]), 1, C.stream_ptr())
+    assert hh.rel_err(hh.from_nhwc(out), ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('sh', [0, 1, 3])
+def test_batchnorm_backward_through_upsampled_sum(dtype, sh):
+    """out = relu(ident + up(bn(y))): d(y), d(gamma), d(beta) vs autograd."""
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cc = 2, 4, 4, 32
+    f = 1 << sh
+    g = torch.Generator().manual_seed(13 + sh)
+    y = _q(torch.randn(N, Cc, H, W, generator=g), dtype).requires_grad_(True)
+    ident = _q(torch.randn(N, Cc, H * f, W * f, generator=g), dtype)
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5)
+        bn.bias.copy_(torch.rand(Cc, generator=g) - 0.5)
+    bn.train()
+    z = bn(y)
+    up = F.interpolate(z, scale_factor=f, mode='nearest') if sh else z
+    out = F.relu(ident + up)
+    gout = _q(torch.randn(out.shape, generator=g), dtype)
+    out.backward(gout)
+    d = hh.DEV
+    mean = y.detach().mean((0, 2, 3))
+    var = y.detach().var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = (bn.weight.detach() * invstd).to(d)
+    shift = (bn.bias.detach() - mean * bn.weight.detach() * invstd).to(d)
+    yd, gd, od = hh.nhwc(y.detach(), dtype), hh.nhwc(gout, dtype), hh.nhwc(_q(out.detach(), dtype), dtype)
+    blocks = C.call('hrnet_reduce_blocks', N, H, W, Cc)
+    part = torch.empty(blocks, 2, Cc, device=d)
+    C.call('hrnet_bn_bwd_reduce', hh.dt_id(dtype), part.data_ptr(), gd.data_ptr(), od.data_ptr(), yd.data_ptr(),
+           scale.data_ptr(), shift.data_ptr(), N, H, W, Cc, sh, 0, C.stream_ptr())
+    dgam, dbet, coef = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d), torch.empty(3 * Cc, device=d)
+    gam_d, mean_d, invstd_d = bn.weight.detach().to(d), mean.to(d), invstd.to(d)   # keep alive across the call
+    C.call('hrnet_bn_bwd_finalize', part.data_ptr(), blocks, Cc, float(N * H * W), gam_d.data_ptr(),
+           mean_d.data_ptr(), invstd_d.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), 0,
+           C.stream_ptr())
+    dy = torch.empty(N, H, W, Cc, dtype=dtype, device=d)
+    C.call('hrnet_grad_term', hh.dt_id(dtype), dy.data_ptr(), gd.data_ptr(), od.data_ptr(), yd.data_ptr(),
+           scale.data_ptr(), shift.data_ptr(), coef.data_ptr(), N, H, W, Cc, sh, 0, 0, C.stream_ptr())
+    tol = 5 * TOL[dtype]
+    assert hh.rel_err(dgam.cpu(), bn.weight.grad) <= tol
+    assert hh.rel_err(dbet.cpu(), bn.bias.grad) <= tol
+    assert hh.rel_err(hh.from_nhwc(dy), y.grad) <= tol
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bilinear_concat_forward_backward(dtype):
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W = 2, 16, 16
+    cs = [32, 64, 128, 256]
+    g = torch.Generator().manual_seed(21)
+    xs = [_q(torch.randn(N, c, H >> j, W >> j, generator=g), dtype).requires_grad_(True) for j, c in enumerate(cs)]
+    ups = [xs[0]] + [F.interpolate(t, size=(H, W), mode='bilinear', align_corners=False) for t in xs[1:]]
+    cat = torch.cat(ups, 1)
+    gcat = _q(torch.randn(cat.shape, generator=g), dtype)
+    cat.backward(gcat)
+    d = hh.DEV
+    xd = [hh.nhwc(t.detach(), dtype) for t in xs]
+    out = torch.empty(N, H, W, sum(cs), dtype=dtype, device=d)
+    hs, ws = [H >> j for j in range(4)], [W >> j for j in range(4)]
+    C.call('hrnet_bilinear_cat', hh.dt_id(dtype), out.data_ptr(), hh.ptr_array(xd), hh.int_array(hs),
+           hh.int_array(ws), hh.int_array(cs), 4, N, H, W, C.stream_ptr())
+    assert hh.rel_err(hh.from_nhwc(out), cat.detach()) <= TOL[dtype]
+    dxs = [torch.empty_like(t) for t in xd]
+    gcd = hh.nhwc(gcat, dtype)
+    C.call('hrnet_bilinear_cat_bwd', hh.dt_id(dtype), gcd.data_ptr(), hh.ptr_array(dxs),
+           hh.int_array(hs), hh.int_array(ws), hh.int_array(cs), 4, N, H, W, 0, C.stream_ptr())
+    for t, dx in zip(xs, dxs):
+        assert hh.rel_err(hh.from_nhwc(dx), t.grad) <= 2 * TOL[dtype]
+
+
+def test_layout_conversions_and_bias_grad():
+    hh = _h()
+    from hipnet import _capi as C
+    for dtype in DTYPES:
+        N, H, W, Cp, Cc = 2, 8, 12, 32, 21
+        g = torch.Generator().manual_seed(2)
+        x = _q(torch.randn(N, Cc, H, W, generator=g), dtype)
+        xd = hh.nhwc(x, dtype, cpad=Cp)
+        out = torch.empty(N, Cc, H, W, device=hh.DEV)
+        C.call('hrnet_nhwc_to_nchw', hh.dt_id(dtype), xd.data_ptr(), out.data_ptr(), N, H, W, Cp, Cc, C.stream_ptr())
+        assert torch.equal(out.cpu(), x)
+        back = torch.full((N, H, W, Cp), 7.0, dtype=dtype, device=hh.DEV)
+        xdev = x.to(hh.DEV)
+        C.call('hrnet_nchw_to_nhwc', hh.dt_id(dtype), xdev.data_ptr(), back.data_ptr(), N, H, W, Cp, Cc,
+               C.stream_ptr())
+        assert torch.equal(back.float().cpu()[..., :Cc], x.permute(0, 2, 3, 1))
+        assert float(back.float().abs()[..., Cc:].max()) == 0.0
+        blocks = C.call('hrnet_reduce_blocks', 1, 1, N * H * W, Cp)
+        scratch = torch.empty(blocks * Cp, device=hh.DEV)
+        db = torch.ones(Cc, device=hh.DEV)
+        C.call('hrnet_bias_grad', hh.dt_id(dtype), xd.data_ptr(), db.data_ptr(), scratch.data_ptr(), N * H * W, Cp, Cc,
+               1, C.stream_ptr())
+        np.testing.assert_allclose(db.cpu().numpy(), 1.0 + x.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_losses_and_decode_against_oracle(golden_dir):
+    """HeatmapLoss / JointsMSELoss / get_final_preds kernels vs the oracle and the reference fixture."""
+    import os
+    hh = _h()
+    from hipnet import _capi as C
+    from oracle import hrnet_cpu as O
+    gz = np.load(os.path.join(golden_dir, 'micro.npz'))
+    d = hh.DEV
+    p, t = torch.from_numpy(gz['hl_pred']), torch.from_numpy(gz['hl_gt'])
+    B, K, H, W = p.shape
+    pd, td = p.to(d), t.to(d)
+    for mode, key in ((0, 'hl_l2'), (1, 'hl_l1')):
+        part, loss = torch.empty(B * K, device=d), torch.empty(1, device=d)
+        C.call('hrnet_heatmap_loss_fwd', pd.data_ptr(), td.data_ptr(), part.data_ptr(), loss.data_ptr(), B * K, H * W,
+               mode, C.stream_ptr())
+        assert abs(loss.item() - float(gz[key])) <= 1e-5 * float(gz[key])
+        pr = p.clone().requires_grad_(True)
+        O.heatmap_loss(pr, t, 'l2' if mode == 0 else 'l1').backward()
+        gout, dp = torch.full((1,), 1.0, device=d), torch.empty_like(pd)
+        C.call('hrnet_heatmap_loss_bwd', pd.data_ptr(), td.data_ptr(), gout.data_ptr(), dp.data_ptr(), B * K, H * W, mode,
+               C.stream_ptr())
+        assert hh.rel_err(dp.cpu(), pr.grad) <= 1e-6
+    # key-point loss
+    pp, pg, vis = (torch.from_numpy(gz[k]) for k in ('jm_pred', 'jm_gt', 'jm_vis'))
+    Bj, Kj = pp.shape[:2]
+    for v, key in ((vis, 'jm_vis_loss'), (None, 'jm_novis_loss'), (torch.zeros(Bj, Kj), 'jm_allinvis_loss')):
+        loss = torch.empty(1, device=d)
+        vd = v.to(d) if v is not None else None
+        ppd, pgd, one = pp.to(d), pg.to(d), torch.ones(1, device=d)   # keep device copies alive
+        C.call('hrnet_joints_loss_fwd', ppd.data_ptr(), pgd.data_ptr(), C.ptr(vd), loss.data_ptr(), Bj, Kj,
+               C.stream_ptr())
+        assert abs(loss.item() - float(gz[key])) <= 1e-5 * max(float(gz[key]), 1.0)
+        pr = pp.clone().requires_grad_(True)
+        O.joints_mse_loss(pr, pg, v).backward()
+        dp = torch.empty(Bj, Kj, 2, device=d)
+        C.call('hrnet_joints_loss_bwd', ppd.data_ptr(), pgd.data_ptr(), C.ptr(vd), one.data_ptr(), dp.data_ptr(), Bj, Kj,
+               C.stream_ptr())
+        assert np.abs(dp.cpu().numpy() - pr.grad.numpy()).max() <= 1e-6
+    # argmax decode incl. ties (bit-exact integer work) and the non-square H-stride rule
+    hm = torch.from_numpy(gz['am_hm'])
+    preds = torch.empty(hm.shape[0], hm.shape[1], 2, device=d)
+    hmd = hm.to(d)
+    C.call('hrnet_decode_argmax', hmd.data_ptr(), preds.data_ptr(), None, hm.shape[0] * hm.shape[1], hm.shape[2],
+           hm.shape[3], 0, C.stream_ptr())
+    assert np.array_equal(preds.cpu().numpy(), gz['am_pred'])
+    ns = torch.randn(2, 3, 4, 6)
+    preds = torch.empty(2, 3, 2, device=d)
+    mv = torch.empty(2, 3, device=d)
+    nsd = ns.to(d)
+    C.call('hrnet_decode_argmax', nsd.data_ptr(), preds.data_ptr(), mv.data_ptr(), 6, 4, 6, 0, C.stream_ptr())
+    assert torch.equal(preds.cpu(), O.get_final_preds(ns, use_softmax=False))
+    C.call('hrnet_decode_argmax', nsd.data_ptr(), preds.data_ptr(), mv.data_ptr(), 6, 4, 6, 1, C.stream_ptr())
+    rp, rm = O.get_max_preds(ns.numpy())
+    assert np.array_equal(preds.cpu().numpy(), rp) and np.array_equal(mv.cpu().numpy()[..., None], rm)
+    # expectation decode + backward
+    hs = torch.rand(2, 21, 64, 64)
+    preds = torch.empty(2, 21, 2, device=d)
+    hsd = hs.to(d)
+    C.call('hrnet_decode_expectation', hsd.data_ptr(), preds.data_ptr(), 42, 64, 64, C.stream_ptr())
+    ref = O.get_final_preds(hs, use_softmax=True)
+    assert hh.rel_err(preds.cpu(), ref) <= 1e-5
+    hr = hs.clone().requires_grad_(True)
+    gp = torch.randn(2, 21, 2)
+    (O.get_final_preds(hr, True) * gp).sum().backward()
+    dh = torch.empty_like(hs, device=d)
+    gpd = gp.to(d)
+    C.call('hrnet_decode_expectation_bwd', gpd.data_ptr(), dh.data_ptr(), 42, 64, 64, 0, C.stream_ptr())
+    assert hh.rel_err(dh.cpu(), hr.grad) <= 1e-6
+
+
+def test_adam_step_matches_torch():
+    hh = _h()
+    from hipnet import _capi as C
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(10000, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-3, weight_decay=1e-4)
+    d = hh.DEV
+    p, m, v = p0.to(d), torch.zeros(10000, device=d), torch.zeros(10000, device=d)
+    for step in range(1, 4):
+        gr = torch.randn(10000, generator=g)
+        p_ref.grad = gr.clone()
+        opt.step()
+        grd = gr.to(d)
+        C.call('hrnet_adam_step', p.data_ptr(), grd.data_ptr(), m.data_ptr(), v.data_ptr(), 10000, 1e-3, 0.9,
+               0.999, 1e-8, 1e-4, step, 1.0, C.stream_ptr())
+    assert np.abs(p.cpu().numpy() - p_ref.detach().numpy()).max() <= 1e-6
+
+
+def test_bad_arguments_raise_not_crash():
+    hh = _h()
+    from hipnet import _capi as C
+    x = torch.zeros(1, 8, 8, 30, device=hh.DEV)
+    with pytest.raises(RuntimeError, match='Cin'):
+        C.call('hrnet_conv2d', 0, x.data_ptr(), x.data_ptr(), None, None, None, x.data_ptr(), None, 1, 8, 8, 30, 8, 8,
+               32, 3, 1, 0, 0, 0, C.stream_ptr())
+    with pytest.raises(RuntimeError, match='kernel size'):
+        C.call('hrnet_conv2d', 0, x.data_ptr(), x.data_ptr(), None, None, None, x.data_ptr(), None, 1, 8, 8, 32, 8, 8,
+               32, 5, 1, 0, 0, 0, C.stream_ptr())
