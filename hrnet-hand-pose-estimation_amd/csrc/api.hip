@@ -51,6 +51,7 @@ extern "C" int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream) {
       case HR_OP_PACK_WEIGHTS: e = hr_launch_pack_weights(op, s); break;
       case HR_OP_BIAS_GRAD: e = hr_launch_bias_grad(op, s); break;
       case HR_OP_FILL: e = hr_launch_fill(op, s); break;
+      case HR_OP_PACK_TABLE: e = hr_launch_pack_table(op, s); break;
       default:
         hr_set_error("program_run: unknown op kind %d at index %d", op.kind, k);
         return HR_E_BADOP;
@@ -88,6 +89,14 @@ extern "C" int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, 
   memcpy(op.i, iv, sizeof(iv));
   op.p[0] = (void*)w_oihw; op.p[1] = packed;
   return hr_launch_pack_weights(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n, int total_blocks,
+                                        hr_stream_t stream) {
+  OP_BEGIN(HR_OP_PACK_TABLE);
+  op.i[0] = dtype; op.i[1] = n; op.i[2] = total_blocks;
+  op.p[0] = (void*)table;
+  return hr_launch_pack_table(op, (hipStream_t)stream);
 }
 
 extern "C" int hrnet_bn_finalize(const float* stats, int tiles, int C, float count, const float* gamma,

@@ -17,31 +17,52 @@ inline unsigned ew_grid(long long n) {
 // ---------------------------------------------------------------------------------------
 // BatchNorm finalize: stats[tiles][2][C] -> scale/shift (+ running stats update)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+// Column sums of rows[n][2][C] (per-workgroup partials) for the block's 32 channels: a block of
+// 1024 threads = 32 channels x 32 row lanes, 4 independent loads in flight per lane (the row count
+// reaches ~4000, and a serial per-channel loop is pure memory latency), f64 accumulation, LDS tree.
+constexpr int FIN_LANES = 32;
+__device__ __forceinline__ void partial_sums(const float* rows, int n, int C, int c, int tl, int cl,
+                                             double (*red)[FIN_LANES][32], double& s1, double& s2) {
+  double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+  if (c < C) {
+    int t = tl;
+    for (; t + FIN_LANES < n; t += 2 * FIN_LANES) {
+      const float x0 = rows[((size_t)t * 2 + 0) * C + c], y0 = rows[((size_t)t * 2 + 1) * C + c];
+      const float x1 = rows[((size_t)(t + FIN_LANES) * 2 + 0) * C + c];
+      const float y1 = rows[((size_t)(t + FIN_LANES) * 2 + 1) * C + c];
+      a0 += (double)x0; b0 += (double)y0; a1 += (double)x1; b1 += (double)y1;
+    }
+    if (t < n) {
+      a0 += (double)rows[((size_t)t * 2 + 0) * C + c];
+      b0 += (double)rows[((size_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[0][tl][cl] = a0 + a1;
+  red[1][tl][cl] = b0 + b1;
+  __syncthreads();
+  for (int s = FIN_LANES / 2; s > 0; s >>= 1) {
+    if (tl < s) {
+      red[0][tl][cl] += red[0][tl + s][cl];
+      red[1][tl][cl] += red[1][tl + s][cl];
+    }
+    __syncthreads();
+  }
+  s1 = red[0][0][cl];
+  s2 = red[1][0][cl];
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* stats, int tiles, int C, float count, const float* gamma, const float* beta,
     float* running_mean, float* running_var, long long* nbt, float momentum, float eps, int training,
     float* scale, float* shift, float* save_mean, float* save_invstd) {
-  // block = 32 channels x 8 tile lanes
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][FIN_LANES][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (training && c < C) {
-    for (int t = tl; t < tiles; t += 8) {
-      s1 += (double)stats[((size_t)t * 2 + 0) * C + c];
-      s2 += (double)stats[((size_t)t * 2 + 1) * C + c];
-    }
-  }
-  red[0][tl][cl] = s1;
-  red[1][tl][cl] = s2;
-  __syncthreads();
+  if (training) partial_sums(stats, tiles, C, c, tl, cl, red, s1, s2);
   if (tl == 0 && c < C) {
     float mean, var;
     if (training) {
-      for (int k = 1; k < 8; ++k) {
-        s1 += red[0][k][cl];
-        s2 += red[1][k][cl];
-      }
       const double m = s1 / (double)count;
       double v = s2 / (double)count - m * m;
       if (v < 0.0) v = 0.0;
@@ -256,26 +277,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     const float* partials, int blocks, int C, float count, const float* gamma, const float* save_mean,
     const float* save_invstd, float* dgamma, float* dbeta, float* coef, int accumulate) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][FIN_LANES][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int t = tl; t < blocks; t += 8) {
-      s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
-      s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
-    }
-  red[0][tl][cl] = s1;
-  red[1][tl][cl] = s2;
-  __syncthreads();
+  partial_sums(partials, blocks, C, c, tl, cl, red, s1, s2);
   if (tl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
-    }
     const double mu = save_mean[c], r = save_invstd[c], g = gamma[c];
     const double dg = r * (s2 - mu * s1);  // sum dz * xhat
     const double db = s1;
@@ -514,6 +524,44 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, T* ou
   }
 }
 
+// all convolutions of the network packed by ONE launch: block b finds its entry by binary search
+template <typename T>
+__global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const HrPackEnt e = tab[lo];
+  const int taps = e.ks * e.ks;
+  const long long total = e.mode == 2 ? (long long)e.Cout_pad * e.Cin_pad : (long long)e.Cout_pad * taps * e.Cin_pad;
+  const float* w = (const float*)e.w;
+  T* out = (T*)e.out;
+  const long long base = (long long)((int)blockIdx.x - e.block0) * 1024;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long idx = base + r * 256 + threadIdx.x;
+    if (idx >= total) break;
+    float val = 0.f;
+    if (e.mode == 0) {
+      const int ci = (int)(idx % e.Cin_pad);
+      const int t = (int)((idx / e.Cin_pad) % taps);
+      const int co = (int)(idx / ((long long)e.Cin_pad * taps));
+      if (co < e.Cout && ci < e.Cin) val = w[((size_t)co * e.Cin + ci) * taps + t];
+    } else if (e.mode == 1) {
+      const int co = (int)(idx % e.Cout_pad);
+      const int tf = (int)((idx / e.Cout_pad) % taps);
+      const int ci = (int)(idx / ((long long)e.Cout_pad * taps));
+      if (co < e.Cout && ci < e.Cin) val = w[((size_t)co * e.Cin + ci) * taps + (taps - 1 - tf)];
+    } else {
+      const int k = (int)(idx % e.Cin_pad);
+      const int co = (int)(idx / e.Cin_pad);
+      if (co < e.Cout && k < taps * e.Cin) val = w[((size_t)co * e.Cin + (k % e.Cin)) * taps + k / e.Cin];
+    }
+    out[idx] = (T)val;
+  }
+}
+
 // column sums of dy[pixels][Cp] (conv bias gradient), two-stage and deterministic
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const char* dy, float* partial, long long pixels,
@@ -555,21 +603,40 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* parti
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
                                                            int Cout, int Cin, int ks, int Cout_real,
                                                            int Cin_real, int kflat, int accumulate) {
+  // block = 64 elements x 4 slab lanes; each lane sums its slabs with 4 loads in flight, LDS adds the
+  // lanes in a fixed order (deterministic)
+  __shared__ float red[4][64];
   const int taps = ks * ks;
   const long long total = (long long)Cout_real * Cin_real * taps;
   const size_t slab_sz = (size_t)Cout * (kflat ? 1 : taps) * Cin;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
     // idx enumerates the slab order (co, tap, ci) so reads stay coalesced
+    const long long idx = base + el;
+    const bool ok = idx < total;
     const int ci = (int)(idx % Cin_real);
     const int t = (int)((idx / Cin_real) % taps);
     const int co = (int)(idx / ((long long)Cin_real * taps));
     const size_t soff = kflat ? ((size_t)co * Cin + (size_t)t * Cin_real + ci)
                               : (((size_t)co * taps + t) * Cin + ci);
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[k * slab_sz + soff];
-    float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
-    *g = accumulate ? *g + s : s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+      int k = sl;
+      for (; k + 12 < nsplit; k += 16) {
+        const float v0 = slabs[(size_t)k * slab_sz + soff], v1 = slabs[(size_t)(k + 4) * slab_sz + soff];
+        const float v2 = slabs[(size_t)(k + 8) * slab_sz + soff], v3 = slabs[(size_t)(k + 12) * slab_sz + soff];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      }
+      for (; k < nsplit; k += 4) s0 += slabs[(size_t)k * slab_sz + soff];
+    }
+    red[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && ok) {
+      const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+      float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
+      *g = accumulate ? *g + s : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -591,7 +658,7 @@ int hr_launch_bn_finalize(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(op.p[1] && op.p[2] && op.p[6] && op.p[7], "bn_finalize: null pointer");
   HR_REQUIRE(training ? (op.p[0] != nullptr && tiles > 0) : (op.p[3] && op.p[4]),
              "bn_finalize: missing statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)op.p[0],
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)op.p[0],
                      tiles, C, op.f[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
                      (float*)op.p[4], (long long*)op.p[5], op.f[1], op.f[2], training, (float*)op.p[6],
                      (float*)op.p[7], (float*)op.p[8], (float*)op.p[9]);
@@ -680,7 +747,7 @@ int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s) {
   const int blocks = op.i[0], C = op.i[1];
   HR_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && op.p[5] && op.p[6],
              "bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)op.p[0],
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)op.p[0],
                      blocks, C, op.f[0], (const float*)op.p[1], (const float*)op.p[2],
                      (const float*)op.p[3], (float*)op.p[4], (float*)op.p[5], (float*)op.p[6], op.i[2]);
   return hr_check_launch("bn_bwd_finalize");
@@ -785,6 +852,16 @@ int hr_launch_pack_weights(const HrOp& op, hipStream_t s) {
   return hr_check_launch("pack_weights");
 }
 
+int hr_launch_pack_table(const HrOp& op, hipStream_t s) {
+  const int n = op.i[1], blocks = op.i[2];
+  HR_REQUIRE(op.p[0] && n >= 1 && blocks >= 1, "pack_weights_table: args");
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(pack_table_kernel<float>, dim3(blocks), dim3(256), 0, s, (const HrPackEnt*)op.p[0], n);
+  else
+    hipLaunchKernelGGL(pack_table_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const HrPackEnt*)op.p[0], n);
+  return hr_check_launch("pack_weights_table");
+}
+
 int hr_launch_bias_grad(const HrOp& op, hipStream_t s) {
   const int pixels = op.i[1], Cp = op.i[2], C = op.i[3];
   const int vec = op.i[0] == HR_F32 ? 4 : 8;
@@ -807,7 +884,9 @@ int hr_launch_wgrad_reduce(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(op.p[0] && op.p[1] && nsplit >= 1, "wgrad_reduce: args");
   HR_REQUIRE(Cout_real <= Cout && (kflat ? Cin_real * ks * ks <= Cin : Cin_real <= Cin), "wgrad_reduce: extents");
   const long long total = (long long)Cout_real * Cin_real * ks * ks;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)op.p[0],
+  long long rgrid = (total + 63) / 64;
+  if (rgrid > 4096) rgrid = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)op.p[0],
                      (float*)op.p[1], nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, op.i[7]);
   return hr_check_launch("wgrad_reduce");
 }

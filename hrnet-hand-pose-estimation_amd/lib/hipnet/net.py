@@ -68,18 +68,27 @@ class HipNet(object):
                 b = BNRec(name, m, self.device)
                 self.bns[name] = b
                 self.bn_list.append(b)
-        self.pack_f, self.pack_d = Program(), Program()
-        for r in self.convs.values():
-            w = r.mod.weight
-            self.pack_f.add(C.OP_PACK_WEIGHTS,
-                            ints=(self.dtid, r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, 2 if r.stem else 0),
-                            ptrs=(C.ptr(w), C.ptr(r.wf)))
-            if r.wd is not None:
-                self.pack_d.add(C.OP_PACK_WEIGHTS,
-                                ints=(self.dtid, r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, 1),
-                                ptrs=(C.ptr(w), C.ptr(r.wd)))
-        self.pack_f.finalize()
-        self.pack_d.finalize()
+        # one launch packs every convolution (forward layouts), one more the transposed dgrad copies
+        self.pack_f = self._pack_program([(r, 2 if r.stem else 0, r.wf) for r in self.convs.values()])
+        self.pack_d = self._pack_program([(r, 1, r.wd) for r in self.convs.values() if r.wd is not None])
+
+    def _pack_program(self, items):
+        import ctypes
+        ents = (C.HrPackEnt * len(items))()
+        block = 0
+        for e, (r, mode, out) in zip(ents, items):
+            taps = r.ks * r.ks
+            total = r.Cout_pad * r.Cin_pad if mode == 2 else r.Cout_pad * taps * r.Cin_pad
+            e.w, e.out = C.ptr(r.mod.weight), C.ptr(out)
+            e.Cout, e.Cin, e.ks, e.Cout_pad, e.Cin_pad, e.mode = r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, mode
+            e.block0 = block
+            block += (total + 1023) // 1024
+        raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._tables = getattr(self, '_tables', []) + [table]
+        prog = Program()
+        prog.add(C.OP_PACK_TABLE, ints=(self.dtid, len(items), block), ptrs=(C.ptr(table),))
+        return prog.finalize()
 
     def pack_weights(self, for_backward):
         """master f32 OIHW -> kernel layouts (forward always, transposed dgrad copy on demand)"""

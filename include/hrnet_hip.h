@@ -56,7 +56,8 @@ enum {
   HR_OP_NCHW_TO_NHWC = 13,
   HR_OP_PACK_WEIGHTS = 14,
   HR_OP_BIAS_GRAD = 15,
-  HR_OP_FILL = 16
+  HR_OP_FILL = 16,
+  HR_OP_PACK_TABLE = 17
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -126,6 +127,15 @@ int hrnet_wgrad_reduce(const float* slabs, float* grad_oihw, int nsplit, int Cou
  */
 int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, int Cout, int Cin, int ks,
                        int Cout_pad, int Cin_pad, int mode, hr_stream_t stream);
+/* The same for every convolution of a network in ONE launch: `table` is a DEVICE array of n
+ * entries; entry e covers blocks [block0, block0 + ceil(elements/1024)); total_blocks = their sum. */
+typedef struct HrPackEnt {
+  const void* w;   /* f32 OIHW master weights */
+  void* out;       /* packed weights */
+  int32_t Cout, Cin, ks, Cout_pad, Cin_pad, mode, block0, reserved;
+} HrPackEnt;
+int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n, int total_blocks,
+                             hr_stream_t stream);
 
 /*
  * BatchNorm2d statistics -> per-channel affine (nn.BatchNorm2d in pose_hrnet.py:34,37,66-73,
