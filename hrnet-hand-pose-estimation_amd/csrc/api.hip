@@ -143,6 +143,17 @@ extern "C" int hrnet_grad_term(int dtype, void* dst, const void* g, const void* 
   return hr_launch_grad_term(op, (hipStream_t)stream);
 }
 
+extern "C" int hrnet_grad_term2(int dtype, void* dst, void* dst2, const void* g, const void* mask_out,
+                                const void* y, const float* scale, const float* shift, const float* coef, int N,
+                                int H, int W, int C, int accumulate, int accumulate2, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_GRAD_TERM);
+  const int iv[9] = {dtype, N, H, W, C, 0, 0, accumulate, accumulate2};
+  memcpy(op.i, iv, sizeof(iv));
+  op.p[0] = dst; op.p[1] = (void*)g; op.p[2] = (void*)mask_out; op.p[3] = (void*)y;
+  op.p[4] = (void*)scale; op.p[5] = (void*)shift; op.p[6] = (void*)coef; op.p[7] = dst2;
+  return hr_launch_grad_term(op, (hipStream_t)stream);
+}
+
 extern "C" int hrnet_bn_bwd_reduce(int dtype, float* partials, const void* g, const void* mask_out,
                                    const void* y, const float* scale, const float* shift, int N, int H,
                                    int W, int C, int sh, int inner_relu, hr_stream_t stream) {

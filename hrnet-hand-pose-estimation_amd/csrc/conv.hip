@@ -33,16 +33,16 @@ struct ConvArgs {
   int N, H, W, Cin;  // stored input
   int Hz, Wz;        // logical input extent (== H, W unless upz)
   int Ho, Wo, Cout;
-  int tiles_y, tiles_x;
+  int tiles_y, tiles_x, total_tiles, tpw;  // tpw = pixel tiles per workgroup
   int in_relu, upz, accumulate;
 };
 
-template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC>
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
 struct ConvCfg {
   static constexpr int VEC = TT<T>::VEC;
   static constexpr int KSTEP = TT<T>::KSTEP;
-  static constexpr int KC = KSTEP;                 // channels staged per chunk
-  static constexpr int VPP = KC / VEC;             // 16-byte vectors per pixel per chunk (= 4)
+  static constexpr int KC = KSTEP * KM;            // channels staged per chunk (KM fragment steps)
+  static constexpr int VPP = KC / VEC;             // 16-byte vectors per pixel per chunk
   static constexpr int TAPS = KS * KS;
   static constexpr int HALO_H = (TH - 1) * STRIDE + KS;
   static constexpr int HALO_W = (TW - 1) * STRIDE + KS;
@@ -50,6 +50,10 @@ struct ConvCfg {
   static constexpr int WROWB = TAPS * KC * (int)sizeof(T) + 16;  // padded weight-row stride
   static constexpr int XBYTES = HALO_H * HALO_W * PIXB;
   static constexpr int WBYTES = BN * WROWB;
+  static constexpr int XVECS = HALO_H * HALO_W * VPP;   // 16-byte vectors of one staged halo chunk
+  static constexpr int WVECS = BN * TAPS * VPP;
+  static constexpr int XV = (XVECS + 255) / 256;        // ... per thread
+  static constexpr int WV = (WVECS + 255) / 256;
   static constexpr int BM = TH * TW;
   static constexpr int PM = BM / WP;   // pixels per wave
   static constexpr int FP = PM / 16;   // pixel fragments per wave
@@ -60,12 +64,19 @@ struct ConvCfg {
   static constexpr int LDSB = (XBYTES + WBYTES) > STATB ? (XBYTES + WBYTES) : STATB;
   static_assert(WP * WC == 4, "4 waves");
   static_assert(PM % 16 == 0 && CN % 16 == 0, "fragment multiples");
-  static_assert(VPP == 4, "staging assumes 4 vectors per pixel");
+  static_assert(256 % VPP == 0, "each thread keeps one channel vector");
+  static_assert(XV <= 31, "validity mask");
 };
 
-template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC>
+// A workgroup walks `tpw` pixel tiles x `nch` K-chunks as a flat sequence of stages. The global
+// loads of stage s+1 are issued into registers before the MFMAs of stage s and written to LDS
+// after them (issue-early / write-late), so HBM/L2 latency hides under the matrix work even at
+// one workgroup per CU. With a single K chunk (Cin <= KC) the weight slice is staged once and
+// stays resident for every tile. BatchNorm statistics accumulate in registers across the tiles
+// and are reduced across lanes / waves once per workgroup.
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
-  using C = ConvCfg<T, KS, STRIDE, TH, TW, BN, WP, WC>;
+  using C = ConvCfg<T, KS, STRIDE, TH, TW, BN, WP, WC, KM>;
   constexpr int VEC = C::VEC;
   __shared__ __attribute__((aligned(16))) char lds[C::LDSB];
   char* xl = lds;
@@ -78,16 +89,16 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   const int wc = wave / WP;
   const int li = lane & 15;
   const int lg = lane >> 4;
-
-  int bid = blockIdx.x;
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int n = bid / a.tiles_y;
   const int n0 = blockIdx.y * BN;
   constexpr int PAD = KS / 2;
-  const int iy0 = ty * TH * STRIDE - PAD;
-  const int ix0 = tx * TW * STRIDE - PAD;
+
+  const int nch = (a.Cin + C::KC - 1) / C::KC;
+  const int tile0 = blockIdx.x * a.tpw;
+  const int ntile = min(a.tpw, a.total_tiles - tile0);
+  const int nstage = ntile * nch;
+  const bool wres = nch == 1;  // weights stay resident in LDS
+  const int v = tid % C::VPP;  // this thread's 16-byte vector within a pixel / weight tap (fixed)
+  const bool has_affine = a.in_scale != nullptr;
 
   // per-lane LDS byte offsets of the MFMA operands
   int aoff[C::FC];
@@ -104,50 +115,101 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     boff[fp] = ((py * STRIDE) * C::HALO_W + px * STRIDE) * C::PIXB + lg * 16;
   }
 
-  f32x4 acc[C::FC][C::FP];
-#pragma unroll
-  for (int fc = 0; fc < C::FC; ++fc)
-#pragma unroll
-    for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging registers of the stage in flight
+  V16 xr[C::XV], wr[C::WV];
+  unsigned xok = 0;
+  float sc[VEC], sh[VEC];
 
-  const int v = tid & 3;  // this thread's 16-byte vector within a weight tap (fixed)
+  auto tile_coords = [&](int t, int& n, int& ty, int& tx) {
+    int b = tile0 + t;
+    tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    ty = b % a.tiles_y;
+    n = b / a.tiles_y;
+  };
 
-  for (int c0 = 0; c0 < a.Cin; c0 += C::KC) {
-    const int c = c0 + v * VEC;
+  auto load_stage = [&](int s) {
+    const int t = s / nch, ch = s - t * nch;
+    int n, ty, tx;
+    tile_coords(t, n, ty, tx);
+    const int iy0 = ty * TH * STRIDE - PAD, ix0 = tx * TW * STRIDE - PAD;
+    const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
-    stage_halo<T, C::KC, C::HALO_H, C::HALO_W, C::PIXB>(xl, a.x, n, a.H, a.W, a.Cin, a.Hz, a.Wz, iy0,
-                                                        ix0, c0, a.in_scale, a.in_shift, a.in_relu,
-                                                        a.upz, tid);
-    // ---- stage the weight slice [BN][TAPS][KC] ----
-    for (int idx = tid; idx < BN * C::TAPS * 4; idx += 256) {
-      const int rt = idx >> 2;
-      const int t = rt % C::TAPS, r = rt / C::TAPS;
-      const int co = n0 + r;
-      V16 val = v16_zero();
-      if (cvalid && co < a.Cout)
-        val = *(const V16*)(a.w + ((size_t)(co * C::TAPS + t) * a.Cin + c) * sizeof(T));
-      *(V16*)(wl + r * C::WROWB + (t * C::KC) * (int)sizeof(T) + v * 16) = val;
+    if (has_affine && cvalid) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        sc[j] = a.in_scale[c + j];
+        sh[j] = a.in_shift[c + j];
+      }
     }
-    __syncthreads();
-    // ---- MFMA over the taps of this chunk ----
+    xok = 0;
 #pragma unroll
-    for (int t = 0; t < C::TAPS; ++t) {
-      const int tapb = ((t / KS) * C::HALO_W + (t % KS)) * C::PIXB;
-      V16 af[C::FC], bf[C::FP];
-#pragma unroll
-      for (int fc = 0; fc < C::FC; ++fc)
-        af[fc] = *(const V16*)(wl + aoff[fc] + t * C::KC * (int)sizeof(T));
-#pragma unroll
-      for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb);
-#pragma unroll
-      for (int fc = 0; fc < C::FC; ++fc)
-#pragma unroll
-        for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
+    for (int k = 0; k < C::XV; ++k) {
+      const int idx = tid + k * 256;
+      const int pix = idx / C::VPP;
+      const int hy = pix / C::HALO_W, hx = pix % C::HALO_W;
+      const int gy = iy0 + hy, gx = ix0 + hx;
+      bool ok = idx < C::XVECS && cvalid && gy >= 0 && gy < a.Hz && gx >= 0 && gx < a.Wz;
+      int sy = gy, sx = gx;
+      if (a.upz) {
+        ok = ok && !((gy | gx) & 1);
+        sy = gy >> 1;
+        sx = gx >> 1;
+        ok = ok && sy < a.H && sx < a.W;
+      }
+      xr[k] = v16_zero();
+      if (ok) {
+        xr[k] = *(const V16*)(a.x + ((size_t)((n * a.H + sy) * a.W + sx) * a.Cin + c) * sizeof(T));
+        xok |= 1u << k;
+      }
     }
-    __syncthreads();
-  }
+    if (!wres || s == 0) {
+#pragma unroll
+      for (int k = 0; k < C::WV; ++k) {
+        const int idx = tid + k * 256;
+        const int rt = idx / C::VPP;
+        const int tp = rt % C::TAPS, r = rt / C::TAPS;
+        const int co = n0 + r;
+        wr[k] = v16_zero();
+        if (idx < C::WVECS && cvalid && co < a.Cout)
+          wr[k] = *(const V16*)(a.w + ((size_t)(co * C::TAPS + tp) * a.Cin + c) * sizeof(T));
+      }
+    }
+  };
 
-  // ---- epilogue: bias, (accumulate), store 4*FC contiguous couts per pixel, BN statistics ----
+  auto store_stage = [&](int s) {
+#pragma unroll
+    for (int k = 0; k < C::XV; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < C::XVECS) {
+        V16 val = xr[k];
+        if (((xok >> k) & 1u) && (has_affine || a.in_relu)) {
+          float f[VEC];
+          v16_unpack<T>(val, f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
+            if (a.in_relu) f[j] = fmaxf(f[j], 0.f);
+          }
+          val = v16_pack<T>(f);
+        }
+        *(V16*)(xl + (idx / C::VPP) * C::PIXB + v * 16) = val;
+      }
+    }
+    if (!wres || s == 0) {
+#pragma unroll
+      for (int k = 0; k < C::WV; ++k) {
+        const int idx = tid + k * 256;
+        if (idx < C::WVECS) {
+          const int rt = idx / C::VPP;
+          const int tp = rt % C::TAPS, r = rt / C::TAPS;
+          *(V16*)(wl + r * C::WROWB + (tp * C::KC) * (int)sizeof(T) + v * 16) = wr[k];
+        }
+      }
+    }
+  };
+
+  f32x4 acc[C::FC][C::FP];
   const int cbase = n0 + wc * C::CN + lg * C::LANE_C;
   const bool cok = cbase < a.Cout;
   float bias[C::LANE_C];
@@ -157,52 +219,88 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < C::LANE_C; ++k) s1[k] = s2[k] = 0.f;
 
+  if (nstage > 0) load_stage(0);
+  for (int s = 0; s < nstage; ++s) {
+    const int t = s / nch, ch = s - t * nch;
+    store_stage(s);
+    __syncthreads();
+    if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
+    if (ch == 0) {
 #pragma unroll
-  for (int fp = 0; fp < C::FP; ++fp) {
-    const int p = wp * C::PM + fp * 16 + li;
-    const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
-    const bool pok = cok && oy < a.Ho && ox < a.Wo;
-    float vals[C::LANE_C];
+      for (int fc = 0; fc < C::FC; ++fc)
 #pragma unroll
-    for (int fc = 0; fc < C::FC; ++fc)
+        for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vals[fc * 4 + r] = acc[fc][fp][r] + bias[fc * 4 + r];
-    if (pok) {
-      char* dst = a.y + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
+    for (int tp = 0; tp < C::TAPS; ++tp) {
+      const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
 #pragma unroll
-      for (int k = 0; k < C::LANE_C; ++k) {
-        s1[k] += vals[k];
-        s2[k] += vals[k] * vals[k];
+      for (int kk = 0; kk < KM; ++kk) {
+        constexpr int KB = C::KSTEP * (int)sizeof(T);   // bytes of one fragment step
+        V16 af[C::FC], bf[C::FP];
+#pragma unroll
+        for (int fc = 0; fc < C::FC; ++fc)
+          af[fc] = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
+#pragma unroll
+        for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb + kk * KB);
+#pragma unroll
+        for (int fc = 0; fc < C::FC; ++fc)
+#pragma unroll
+          for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
       }
+    }
+    if (ch == nch - 1) {
+      // ---- tile epilogue: bias, (accumulate), 4*FC contiguous couts per pixel, BN statistics ----
+      int n, ty, tx;
+      tile_coords(t, n, ty, tx);
 #pragma unroll
-      for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
-        if constexpr (C::LANE_C >= VEC) {
-          if (a.accumulate) {
-            float old[VEC];
-            v16_unpack<T>(*(const V16*)(dst + k0 * sizeof(T)), old);
+      for (int fp = 0; fp < C::FP; ++fp) {
+        const int p = wp * C::PM + fp * 16 + li;
+        const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+        const bool pok = cok && oy < a.Ho && ox < a.Wo;
+        float vals[C::LANE_C];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) vals[k0 + j] += old[j];
+        for (int fc = 0; fc < C::FC; ++fc) {
+          vals[fc * 4 + 0] = acc[fc][fp].x + bias[fc * 4 + 0];
+          vals[fc * 4 + 1] = acc[fc][fp].y + bias[fc * 4 + 1];
+          vals[fc * 4 + 2] = acc[fc][fp].z + bias[fc * 4 + 2];
+          vals[fc * 4 + 3] = acc[fc][fp].w + bias[fc * 4 + 3];
+        }
+        if (pok) {
+          char* dst = a.y + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
+#pragma unroll
+          for (int k = 0; k < C::LANE_C; ++k) {
+            s1[k] += vals[k];
+            s2[k] += vals[k] * vals[k];
           }
-          *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
-        } else {
-          // LANE_C == 4 with bf16: one 8-byte store
-          bf16x4 o;
-          if (a.accumulate) {
-            const bf16x4 old = *(const bf16x4*)dst;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vals[j] += (float)old[j];
+          for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
+            if constexpr (C::LANE_C >= VEC) {
+              if (a.accumulate) {
+                float old[VEC];
+                v16_unpack<T>(*(const V16*)(dst + k0 * sizeof(T)), old);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) vals[k0 + j] += old[j];
+              }
+              *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
+            } else {
+              // LANE_C == 4 with bf16: one 8-byte store
+              if (a.accumulate) {
+                const bf16x4 old = *(const bf16x4*)dst;
+                vals[0] += (float)old.x; vals[1] += (float)old.y; vals[2] += (float)old.z; vals[3] += (float)old.w;
+              }
+              const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
+              *(bf16x4*)dst = o;
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16_t)vals[j];
-          *(bf16x4*)dst = o;
         }
       }
     }
+    __syncthreads();  // every wave is done reading this stage's LDS image
   }
 
   if (a.stats) {
-    __syncthreads();  // LDS reuse
-    float* sl = (float*)lds;  // [WP][2][BN]
+    float* sl = (float*)lds;  // [WP][2][BN] (the loop ended on a barrier: LDS is free)
 #pragma unroll
     for (int k = 0; k < C::LANE_C; ++k) {
       s1[k] = wave_sum16(s1[k]);
@@ -230,32 +328,53 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 
 // ---- tile configuration choice (host) --------------------------------------------------
 struct TileChoice {
-  int th, tw, bn, id;
+  int th, tw, bn, id, tpw, gx;
 };
 
-TileChoice choose_tile(int Ho, int Wo, int Cout, int ks, int stride) {
+TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride) {
   // id: 0 = 16x16/BN32 (4x1 waves), 1 = 8x16/BN64 (2x2), 2 = 8x8/BN64 (2x2), 3 = 8x8/BN32 (2x2)
-  if (stride == 2) return Cout >= 64 ? TileChoice{8, 8, 64, 2} : TileChoice{8, 8, 32, 3};
-  if (Cout <= 32) return (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0} : TileChoice{8, 8, 32, 3};
-  if (Wo >= 16 && Ho >= 16) return TileChoice{8, 16, 64, 1};
-  return TileChoice{8, 8, 64, 2};
+  TileChoice tc;
+  if (stride == 2) tc = Cout >= 64 ? TileChoice{8, 8, 64, 2, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
+  else if (Cout <= 32) tc = (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
+  else if (Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 64, 1, 1, 0};
+  else tc = TileChoice{8, 8, 64, 2, 1, 0};
+  const int tiles = N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
+  int gy = (Cout + tc.bn - 1) / tc.bn;
+  // few workgroups on small maps: halve BN for twice the workgroups (latency hiding beats reuse)
+  if (tc.bn == 64 && tiles * gy < 512) {
+    tc.bn = 32;
+    tc.id = 3;
+    if (tc.th != 8 || tc.tw != 8) { tc.th = 8; tc.tw = 8; }
+    gy = (Cout + 31) / 32;
+  }
+  const int tiles2 = N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
+  // about 3 resident workgroups per CU; the rest of the tiles are walked by the same workgroups
+  int tpw = (tiles2 * gy + 767) / 768;
+  if (tpw < 1) tpw = 1;
+  if (tpw > 8) tpw = 8;
+  tc.tpw = tpw;
+  tc.gx = (tiles2 + tpw - 1) / tpw;
+  return tc;
 }
 
 template <typename T, int KS, int STRIDE>
 int launch_cfg(const ConvArgs& a, const TileChoice& tc, int N, hipStream_t s) {
-  dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x), (unsigned)((a.Cout + tc.bn - 1) / tc.bn));
+  dim3 grid((unsigned)tc.gx, (unsigned)((a.Cout + tc.bn - 1) / tc.bn));
+  // K depth per stage: a 1x1 conv has one tap, so it stages 4 fragment steps per barrier pair
+  constexpr int KM1 = KS == 1 ? 4 : 1;
+  constexpr int KM3 = KS == 1 ? 4 : 2;   // 8x8 / BN32 tiles have LDS room for two steps
   switch (tc.id) {
     case 0:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 16, 16, 32, 4, 1>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 16, 16, 32, 4, 1, KM1>), grid, dim3(256), 0, s, a);
       break;
     case 1:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 16, 64, 2, 2>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 16, 64, 2, 2, KM1>), grid, dim3(256), 0, s, a);
       break;
     case 2:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 64, 2, 2>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 64, 2, 2, KM1>), grid, dim3(256), 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 32, 2, 2>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 32, 2, 2, KM3>), grid, dim3(256), 0, s, a);
       break;
   }
   return hr_check_launch("conv2d");
@@ -271,8 +390,7 @@ int launch_t(const ConvArgs& a, const TileChoice& tc, int N, int ks, int stride,
 }  // namespace
 
 extern "C" int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride) {
-  const TileChoice tc = choose_tile(Ho, Wo, Cout, ks, stride);
-  return N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
+  return choose_tile(N, Ho, Wo, Cout, ks, stride).gx;   // one statistics row per workgroup
 }
 
 int hr_launch_conv(const HrOp& op, hipStream_t s) {
@@ -310,9 +428,11 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
                "conv2d: output %dx%d does not match input %dx%d ks=%d stride=%d", Ho, Wo, H, W, ks, stride);
     a.Hz = H; a.Wz = W;
   }
-  const TileChoice tc = choose_tile(Ho, Wo, Cout, ks, op.i[9]);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, op.i[9]);
   a.tiles_y = (Ho + tc.th - 1) / tc.th;
   a.tiles_x = (Wo + tc.tw - 1) / tc.tw;
+  a.total_tiles = N * a.tiles_y * a.tiles_x;
+  a.tpw = tc.tpw;
   // the tile choice is keyed on the ORIGINAL stride so hrnet_conv_tiles() agrees; a upz conv
   // runs the stride-1 kernel with that tile
   if (dtype == HR_F32) return launch_t<float>(a, tc, N, ks, stride, s);
@@ -334,11 +454,12 @@ extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float
 
 // Demangled-style name of the kernel instantiation hrnet_conv2d launches for this shape (so that
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
-extern "C" int hrnet_conv_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, int upz,
+extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cout, int ks, int stride, int upz,
                                       char* buf, int buflen) {
-  const TileChoice tc = choose_tile(Ho, Wo, Cout, ks, stride);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride);
   static const int wp[4] = {4, 2, 2, 2}, wc[4] = {1, 2, 2, 2};
   const int kstride = (ks == 1 || upz) ? 1 : stride;
-  return snprintf(buf, buflen, "conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",
-                  ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id]);
+  const int km = ks == 1 ? 4 : (tc.id == 3 ? 2 : 1);
+  return snprintf(buf, buflen, "conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",
+                  ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
 }

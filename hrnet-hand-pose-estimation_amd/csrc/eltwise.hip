@@ -158,7 +158,8 @@ struct GradArgs {
   const float* shift;
   const float* coef;
   float* partials;
-  int N, H, W, C, sh, inner_relu, accumulate;
+  char* dst2;   // optional second destination: dst2 (+)= dz (the residual / identity term of the same sum)
+  int N, H, W, C, sh, inner_relu, accumulate, accumulate2;
 };
 
 template <typename T>
@@ -230,6 +231,16 @@ __global__ __launch_bounds__(256) void grad_term_kernel(GradArgs a) {
       for (int j = 0; j < VEC; ++j) o[j] += old[j];
     }
     *(V16*)d = v16_pack<T>(o);
+    if (a.dst2) {
+      char* d2 = a.dst2 + (size_t)idx * 16;
+      if (a.accumulate2) {
+        float old[VEC];
+        v16_unpack<T>(*(const V16*)d2, old);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dz[j] += old[j];
+      }
+      *(V16*)d2 = v16_pack<T>(dz);
+    }
   }
 }
 
@@ -696,10 +707,13 @@ int hr_launch_sum_terms(const HrOp& op, hipStream_t s) {
 static int fill_grad_args(const HrOp& op, GradArgs& a, bool reduce) {
   a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.sh = op.i[5]; a.inner_relu = op.i[6];
   a.accumulate = reduce ? 0 : op.i[7];
+  a.accumulate2 = reduce ? 0 : op.i[8];
+  a.dst2 = reduce ? nullptr : (char*)op.p[7];
   if (reduce) {
     a.partials = (float*)op.p[0]; a.dst = nullptr; a.coef = nullptr;
   } else {
     a.dst = (char*)op.p[0]; a.partials = nullptr; a.coef = (const float*)op.p[6];
+    HR_REQUIRE(!a.dst2 || (a.sh == 0 && !a.inner_relu), "grad_term: dst2 needs sh=0 and no inner ReLU");
   }
   a.g = (const char*)op.p[1]; a.mask = (const char*)op.p[2]; a.y = (const char*)op.p[3];
   a.scale = (const float*)op.p[4]; a.shift = (const float*)op.p[5];
@@ -723,9 +737,10 @@ int hr_launch_grad_term(const HrOp& op, hipStream_t s) {
 
 extern "C" int hrnet_reduce_blocks(int N, int H, int W, int C) {
   const long long npix = (long long)N * H * W;
+  // 8 blocks per CU keep ~100 KB of loads in flight per CU (these passes are latency-bound otherwise)
   long long b = npix / 64;
   if (b < 1) b = 1;
-  if (b > 512) b = 512;
+  if (b > 2048) b = 2048;
   (void)C;
   return (int)b;
 }

@@ -41,7 +41,7 @@ _SIGS = {
     'hrnet_program_run': [ctypes.POINTER(HrOp), _c_int, _c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
     'hrnet_conv_tiles': [_c_int] * 6,
-    'hrnet_conv_kernel_name': [_c_int] * 7 + [ctypes.c_char_p, _c_int],
+    'hrnet_conv_kernel_name': [_c_int] * 8 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
     'hrnet_wgrad_splits': [_c_int] * 8,
@@ -52,6 +52,7 @@ _SIGS = {
                          + [_c_vp] * 4 + [_c_vp],
     'hrnet_sum_terms': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_vp],
     'hrnet_grad_term': [_c_int] + [_c_vp] * 7 + [_c_int] * 7 + [_c_vp],
+    'hrnet_grad_term2': [_c_int] + [_c_vp] * 8 + [_c_int] * 6 + [_c_vp],
     'hrnet_bn_bwd_reduce': [_c_int] + [_c_vp] * 6 + [_c_int] * 6 + [_c_vp],
     'hrnet_reduce_blocks': [_c_int] * 4,
     'hrnet_bn_bwd_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 6 + [_c_int, _c_vp],

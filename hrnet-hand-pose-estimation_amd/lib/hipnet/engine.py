@@ -328,9 +328,10 @@ class Plan(object):
         return outs
 
     # ---- backward recording ---------------------------------------------------------------
-    def _bn_backward(self, y, g_src, mask, sh, inner_relu):
+    def _bn_backward(self, y, g_src, mask, sh, inner_relu, extra=None):
         """BatchNorm backward for raw act y: reads the upstream gradient from g_src (pooled over
-        2^sh blocks, masked by mask>0 and the BN's own ReLU), writes d(raw) into y.g."""
+        2^sh blocks, masked by mask>0 and the BN's own ReLU), writes d(raw) into y.g. `extra`: an
+        identity term of the same sum whose gradient (the same dz) is written by the same pass."""
         b = y.bn
         blocks = C.call('hrnet_reduce_blocks', y.N, y.H, y.W, y.C)
         self.max_bwd_part = max(self.max_bwd_part, blocks * 2 * y.C)
@@ -342,8 +343,14 @@ class Plan(object):
                          ptrs=(None, C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
                                C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
         self._scratch(self.bwd, j, 0, 'bwdpart')
-        self.bwd.add(C.OP_GRAD_TERM, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0, 0),
-                     ptrs=(C.ptr(y.g), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.coef)))
+        ints = [self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0, 0, 0]
+        ptrs = [C.ptr(y.g), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.coef), None]
+        if extra is not None:
+            assert sh == 0 and not inner_relu
+            ints[8] = 1 if extra.ginit else 0
+            ptrs[7] = C.ptr(extra.g)
+            extra.ginit = True
+        self.bwd.add(C.OP_GRAD_TERM, ints=ints, ptrs=ptrs)
         y.bn_done = True
         y.ginit = True
 
@@ -383,11 +390,19 @@ class Plan(object):
                     # no consumer produced a gradient (cannot happen for this network)
                     raise RuntimeError('no gradient reaches ' + out.name)
                 mask = C.ptr(out.t) if relu_out else None
+                fusable = [t for t, sh in zip(terms, shifts)
+                           if t.act.bn is not None and t.act.nuse == 1 and sh == 0 and not t.relu]
+                plain = [t for t, sh in zip(terms, shifts) if not (t.act.bn is not None and t.act.nuse == 1)]
+                # one BN term and one identity/accumulating term share dz: written by the same pass
+                paired = (fusable[0], plain[0]) if fusable and plain else (None, None)
                 for t, sh in zip(terms, shifts):
                     a = t.act
+                    if t is paired[1]:
+                        continue
                     if a.bn is not None and a.nuse == 1 and self.training:
                         # single consumer: fuse pooling + masks + BatchNorm backward
-                        self._bn_backward(a, C.ptr(out.g), mask, sh, t.relu)
+                        self._bn_backward(a, C.ptr(out.g), mask, sh, t.relu,
+                                          extra=paired[1].act if t is paired[0] else None)
                     else:
                         # accumulate d(post-activation value); BN backward runs at the producer
                         assert sh == 0

@@ -96,8 +96,8 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                  int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int upz,
                  int in_relu, int accumulate, hr_stream_t stream);
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
-int hrnet_conv_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, int upz, char* buf,
-                           int buflen);
+int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cout, int ks, int stride, int upz,
+                           char* buf, int buflen);
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
@@ -170,6 +170,11 @@ int hrnet_sum_terms(int dtype, void* out, int N, int Ho, int Wo, int C, int nter
 int hrnet_grad_term(int dtype, void* dst, const void* g, const void* mask_out, const void* y,
                     const float* scale, const float* shift, const float* coef, int N, int H, int W,
                     int C, int sh, int inner_relu, int accumulate, hr_stream_t stream);
+/* same with sh = 0 and no inner ReLU, plus a second destination dst2 (+)= dz: the BatchNorm term and
+ * the residual/identity term of one sum (pose_hrnet.py:54-55) share dz and are written in one pass */
+int hrnet_grad_term2(int dtype, void* dst, void* dst2, const void* g, const void* mask_out, const void* y,
+                     const float* scale, const float* shift, const float* coef, int N, int H, int W, int C,
+                     int accumulate, int accumulate2, hr_stream_t stream);
 /* partials[blocks][2][C]: sum(dz), sum(dz*y) with dz as above; blocks = hrnet_reduce_blocks() */
 int hrnet_bn_bwd_reduce(int dtype, float* partials, const void* g, const void* mask_out,
                         const void* y, const float* scale, const float* shift, int N, int H, int W,

@@ -27,11 +27,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_shape_helpers_are_pure():
     from hipnet import _capi as C
-    # 64 images of 64x64 maps with 32 channels: 16x16 tiles
-    assert C.call('hrnet_conv_tiles', 64, 64, 64, 32, 3, 1) == 64 * 16
+    # statistics rows = workgroups along x: 64 images x 16 tiles of 16x16, a few tiles per workgroup
+    rows = C.call('hrnet_conv_tiles', 64, 64, 64, 32, 3, 1)
+    assert 128 <= rows <= 64 * 16 and (64 * 16) % rows == 0
     assert C.call('hrnet_conv_tiles', 2, 8, 8, 256, 3, 1) == 2
     assert C.call('hrnet_wgrad_splits', C.HR_BF16, 64, 64, 64, 32, 32, 3, 1) >= 1
-    assert 1 <= C.call('hrnet_reduce_blocks', 64, 64, 64, 32) <= 512
+    assert 1 <= C.call("hrnet_reduce_blocks", 64, 64, 64, 32) <= 2048
 
 
 def test_config_merges_reference_style_yaml_and_freezes():
