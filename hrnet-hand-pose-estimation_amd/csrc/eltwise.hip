@@ -604,11 +604,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* dy, float* part
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* partial, float* dbias,
                                                               int blocks, int Cp, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * Cp + c];
-  dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+  // block = 32 channels x 8 row lanes
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    int b = tl;
+    for (; b + 8 < blocks; b += 16) {
+      const float x0 = partial[(size_t)b * Cp + c], x1 = partial[(size_t)(b + 8) * Cp + c];
+      s0 += (double)x0; s1 += (double)x1;
+    }
+    if (b < blocks) s0 += (double)partial[(size_t)b * Cp + c];
+  }
+  red[tl][cl] = s0 + s1;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    double s = 0.0;
+    for (int k = 0; k < 8; ++k) s += red[k][cl];
+    dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+  }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
@@ -888,7 +903,7 @@ int hr_launch_bias_grad(const HrOp& op, hipStream_t s) {
   else
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const char*)op.p[0],
                        (float*)op.p[2], (long long)pixels, Cp);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)op.p[2],
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)op.p[2],
                      (float*)op.p[1], blocks, Cp, C, op.i[4]);
   return hr_check_launch("bias_grad");
 }

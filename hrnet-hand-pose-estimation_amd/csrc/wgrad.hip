@@ -101,25 +101,90 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int f = 0; f < FCOW; ++f) acc[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+  // ---- staging registers: the next tile's loads are issued before the MFMAs of the current one
+  // and written to LDS after them (issue-early / write-late) ----
+  constexpr int VPP = KC / VEC;                          // 16-byte vectors per halo pixel
+  constexpr int XVECS = HALO_H * HALO_W * VPP, DVECS = BM * DVPP;
+  constexpr int XV = (XVECS + 255) / 256, DV = (DVECS + 255) / 256;
+  static_assert(256 % VPP == 0 && XV <= 31, "staging layout");
+  V16 xr[XV], dr[DV];
+  unsigned xok = 0;
+  const int xv = tid % VPP;
+  const int xc = c0 + xv * VEC;
+  const bool xcvalid = xc < a.Cin;
+  const bool has_affine = a.in_scale != nullptr;
+  float sc[VEC], sh[VEC];
+  if (has_affine && xcvalid) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sc[j] = a.in_scale[xc + j];
+      sh[j] = a.in_shift[xc + j];
+    }
+  }
+
+  auto load_tile = [&](int tile) {
     int b = tile;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
     const int ty = b % a.tiles_y;
     const int n = b / a.tiles_y;
-    stage_halo<T, KC, HALO_H, HALO_W, PIXB>(xl, a.x, n, a.H, a.W, a.Cin, a.H, a.W,
-                                            ty * TH * STRIDE - PAD, tx * TW * STRIDE - PAD, c0,
-                                            a.in_scale, a.in_shift, a.in_relu, 0, tid);
-    for (int idx = tid; idx < BM * DVPP; idx += 256) {
+    const int iy0 = ty * TH * STRIDE - PAD, ix0 = tx * TW * STRIDE - PAD;
+    xok = 0;
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int idx = tid + k * 256;
+      const int pix = idx / VPP;
+      const int gy = iy0 + pix / HALO_W, gx = ix0 + pix % HALO_W;
+      const bool ok = idx < XVECS && xcvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      xr[k] = v16_zero();
+      if (ok) {
+        xr[k] = *(const V16*)(a.x + ((size_t)((n * a.H + gy) * a.W + gx) * a.Cin + xc) * sizeof(T));
+        xok |= 1u << k;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      const int idx = tid + k * 256;
       const int p = idx / DVPP, v = idx % DVPP;
       const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
       const int co = co0 + v * VEC;
-      V16 val = v16_zero();
-      if (oy < a.Ho && ox < a.Wo && co < a.Cout)
-        val = *(const V16*)(a.dy + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * sizeof(T));
-      *(V16*)(dl + p * DYB + v * 16) = val;
+      dr[k] = v16_zero();
+      if (idx < DVECS && oy < a.Ho && ox < a.Wo && co < a.Cout)
+        dr[k] = *(const V16*)(a.dy + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * sizeof(T));
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < XVECS) {
+        V16 val = xr[k];
+        if (((xok >> k) & 1u) && (has_affine || a.in_relu)) {
+          float f[VEC];
+          v16_unpack<T>(val, f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
+            if (a.in_relu) f[j] = fmaxf(f[j], 0.f);
+          }
+          val = v16_pack<T>(f);
+        }
+        *(V16*)(xl + (idx / VPP) * PIXB + xv * 16) = val;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < DVECS) *(V16*)(dl + (idx / DVPP) * DYB + (idx % DVPP) * 16) = dr[k];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.total_tiles) load_tile(tile);
+  for (; tile < a.total_tiles; tile += gridDim.x) {
+    store_tile();
     __syncthreads();
+    if (tile + (int)gridDim.x < a.total_tiles) load_tile(tile + gridDim.x);  // in flight during the MFMAs
 #pragma unroll 2
     for (int ks = 0; ks < BM / KSTEP; ++ks) {
       const int p0 = ks * KSTEP + lg * VEC;  // first pixel of this lane group
@@ -149,12 +214,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (fr < NFR) {
       const int t = fr / FCI, ci = c0 + (fr % FCI) * 16 + li;
 #pragma unroll
-      for (int f = 0; f < FCOW; ++f)
+      for (int f = 0; f < FCOW; ++f) {
+        const int co = co0 + (wco * FCOW + f) * 16 + lg * 4;
+        const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + (wco * FCOW + f) * 16 + lg * 4 + r;
-          if (co < a.Cout && ci < a.Cin) slab[((size_t)co * TAPS + t) * a.Cin + ci] = acc[j][f][r];
-        }
+        for (int r = 0; r < 4; ++r)
+          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * TAPS + t) * a.Cin + ci] = v4[r];
+      }
     }
   }
 }
