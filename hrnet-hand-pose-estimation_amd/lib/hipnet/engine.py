@@ -16,6 +16,7 @@ Dataflow conventions
         gradient w.r.t. the raw conv output (two-stage deterministic reductions).
 """
 import ctypes
+import os
 
 import torch
 
@@ -76,11 +77,18 @@ class ConvRec(object):
 
 
 class Program(object):
-    """A recorded list of HrOp, run with one C call."""
+    """A recorded list of HrOp. Ops carry a lane; between a 'fork' and a 'join' marker the lanes are
+    independent chains (the branches of one HighResolutionModule) and run on separate HIP streams,
+    so the latency-bound low-resolution convolutions overlap the bandwidth-bound high-resolution
+    ones. Without side streams everything runs in order on the current stream (one C call)."""
 
     def __init__(self):
         self.ops = []
+        self.lanes = []
+        self.marks = []      # (position, 'fork'|'join', lanes)
+        self.lane = 0
         self._arr = None
+        self._segs = None
 
     def add(self, kind, ints=(), floats=(), ptrs=()):
         op = C.HrOp()
@@ -92,11 +100,30 @@ class Program(object):
         for k, v in enumerate(ptrs):
             op.p[k] = v
         self.ops.append(op)
+        self.lanes.append(self.lane)
         self._arr = None
         return len(self.ops) - 1
 
+    def mark(self, what, lanes):
+        self.marks.append((len(self.ops), what, tuple(lanes)))
+
     def finalize(self):
-        self._arr = (C.HrOp * len(self.ops))(*self.ops)
+        self._arr = (C.HrOp * len(self.ops))(*self.ops) if self.ops else None
+        segs, marks, mi, lo = [], sorted(self.marks, key=lambda m: m[0]), 0, 0
+        n = len(self.ops)
+        for i in range(n + 1):
+            while mi < len(marks) and marks[mi][0] == i:
+                if lo < i:
+                    segs.append(('run', lo, i, self.lanes[lo]))
+                    lo = i
+                segs.append((marks[mi][1], i, i, marks[mi][2]))
+                mi += 1
+            if i < n and i > lo and self.lanes[i] != self.lanes[lo]:
+                segs.append(('run', lo, i, self.lanes[lo]))
+                lo = i
+        if lo < n:
+            segs.append(('run', lo, n, self.lanes[lo]))
+        self._segs = segs
         return self
 
     def set_ptr(self, op_index, slot, value):
@@ -105,13 +132,38 @@ class Program(object):
     def set_int(self, op_index, slot, value):
         self._arr[op_index].i[slot] = value
 
-    def run(self, lo=0, hi=None):
-        if self._arr is None:
+    def _call(self, lo, hi, stream_handle):
+        base = ctypes.cast(ctypes.byref(self._arr, lo * ctypes.sizeof(C.HrOp)), ctypes.POINTER(C.HrOp))
+        C.call('hrnet_program_run', base, hi - lo, stream_handle)
+
+    def run(self, lo=0, hi=None, streams=None):
+        if self._segs is None:
             self.finalize()
-        hi = len(self.ops) if hi is None else hi
-        if hi > lo:
-            base = ctypes.cast(ctypes.byref(self._arr, lo * ctypes.sizeof(C.HrOp)), ctypes.POINTER(C.HrOp))
-            C.call('hrnet_program_run', base, hi - lo, C.stream_ptr())
+        n = len(self.ops)
+        hi = n if hi is None else hi
+        if hi <= lo:
+            return
+        if streams is None or not self.marks:
+            self._call(lo, hi, C.stream_ptr())
+            return
+        main = torch.cuda.current_stream()
+        for what, a, b, arg in self._segs:
+            if what == 'run':
+                a2, b2 = max(a, lo), min(b, hi)
+                if a2 < b2:
+                    st = main if arg == 0 else streams[arg]
+                    self._call(a2, b2, st.cuda_stream)
+            elif lo <= a < hi or (a == hi == n):
+                if what == 'fork':
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    for l in arg:
+                        streams[l].wait_event(ev)
+                else:
+                    for l in arg:
+                        ev = torch.cuda.Event()
+                        ev.record(streams[l])
+                        main.wait_event(ev)
 
     def __len__(self):
         return len(self.ops)
@@ -140,6 +192,9 @@ class Plan(object):
         self.max_bwd_part = 0
         self.pending = []         # (program, op_index, slot, kind) scratch pointers to patch
         self.bucket_marks = []    # backward op indices after which a gradient bucket is complete
+        self.tape_lanes = []
+        self.nlanes = 4 if os.environ.get('HRNET_LANES', '1') != '0' else 1
+        self.streams = None
         self._build()
 
     # ---- allocation helpers -----------------------------------------------------------
@@ -158,6 +213,10 @@ class Plan(object):
 
     def _scratch(self, prog, idx, slot, kind):
         self.pending.append((prog, idx, slot, kind))
+
+    def _tape(self, entry):
+        self.tape.append(entry)
+        self.tape_lanes.append(self.fwd.lane)
 
     # ---- forward recording -------------------------------------------------------------
     def conv(self, xin, crec, stride=1, bnrec=None, relu=False, name=None):
@@ -193,7 +252,7 @@ class Plan(object):
                                        C.ptr(m.running_var), C.ptr(m.num_batches_tracked), C.ptr(bnrec.scale),
                                        C.ptr(bnrec.shift), C.ptr(bnrec.mean), C.ptr(bnrec.invstd)))
                 self._scratch(self.fwd, j, 0, 'stats')
-        self.tape.append(('conv', xin, crec, stride, y, bnrec))
+        self._tape(('conv', xin, crec, stride, y, bnrec))
         return Val(y, bnrec, relu)
 
     def sum(self, terms, shifts, relu_out, name):
@@ -210,7 +269,7 @@ class Plan(object):
         self.fwd.add(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
         for t in terms:
             t.act.nuse += 1
-        self.tape.append(('sum', list(terms), list(shifts), relu_out, out))
+        self._tape(('sum', list(terms), list(shifts), relu_out, out))
         return Val(out)
 
     def bilinear_cat(self, vals, name):
@@ -225,7 +284,7 @@ class Plan(object):
         for v in vals:
             assert v.bn is None and not v.relu
             v.act.nuse += 1
-        self.tape.append(('cat', list(vals), cat))
+        self._tape(('cat', list(vals), cat))
         return Val(cat)
 
     # ---- network walk (reference: PoseHighResolutionNet.forward, pose_hrnet.py:511-568) ----
@@ -299,12 +358,21 @@ class Plan(object):
         cv, bn = self.net.convs, self.net.bns
         nb = len(xs)
         xs = list(xs)
+        side = [i for i in range(1, nb) if i < self.nlanes]
+        if side:
+            self.fwd.mark('fork', side)
+            self._tape(('fork', side))
         for i in range(nb):
+            self.fwd.lane = i if i in side else 0
             for k in range(num_blocks[i]):
                 b = '{}.branches.{}.{}'.format(pre, i, k)
                 a = self.conv(xs[i], cv[b + '.conv1'], 1, bn[b + '.bn1'], relu=True)
                 c = self.conv(a, cv[b + '.conv2'], 1, bn[b + '.bn2'], relu=False)
                 xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
+        self.fwd.lane = 0
+        if side:
+            self.fwd.mark('join', side)
+            self._tape(('join', side))
         outs = []
         for i in range(nb):
             terms, shifts = [], []
@@ -369,7 +437,15 @@ class Plan(object):
                 for t in e[1]:
                     relu_of[id(t.act)] = t.relu
         self.inter_gop = None
-        for e in reversed(self.tape):
+        in_region = False
+        for e, lane in reversed(list(zip(self.tape, self.tape_lanes))):
+            self.bwd.lane = lane
+            if e[0] in ('fork', 'join'):
+                # a forward join is the backward fork of the same lanes, and vice versa
+                self.bwd.lane = 0
+                self.bwd.mark('fork' if e[0] == 'join' else 'join', e[1])
+                in_region = e[0] == 'join'
+                continue
             if e[0] == 'cat':
                 _, vals, cat = e
                 hs = [v.act.H for v in vals] + [0] * (4 - len(vals))
@@ -447,16 +523,26 @@ class Plan(object):
                                        1 if stride == 2 else 0, 0, 1 if x.ginit else 0),
                                  ptrs=(C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None))
                     x.ginit = True
-                self.bucket_marks.append((len(self.bwd), crec.prefix))
+                if lane == 0 and not in_region:
+                    self.bucket_marks.append((len(self.bwd), crec.prefix))
 
     def _resolve_scratch(self):
-        stats = self._f32(max(self.max_stats, 1))
-        slab = self._f32(max(self.max_slab, 1))
-        part = self._f32(max(self.max_bwd_part, 1))
-        table = {'stats': stats, 'slab': slab, 'bwdpart': part}
+        sizes = {'stats': max(self.max_stats, 1), 'slab': max(self.max_slab, 1), 'bwdpart': max(self.max_bwd_part, 1)}
+        table = {}
         for prog, idx, slot, kind in self.pending:
-            prog.ops[idx].p[slot] = C.ptr(table[kind])
+            key = (kind, prog.lanes[idx])      # concurrent lanes must not share scratch
+            if key not in table:
+                table[key] = self._f32(sizes[kind])
+            prog.ops[idx].p[slot] = C.ptr(table[key])
         self.pending = []
+        self.bwd.lane = 0
+
+    def _side_streams(self):
+        if self.nlanes <= 1:
+            return None
+        if self.streams is None:
+            self.streams = [None] + [torch.cuda.Stream(device=self.dev) for _ in range(self.nlanes - 1)]
+        return self.streams
 
     # ---- execution --------------------------------------------------------------------------
     def run_forward(self, x):
@@ -467,7 +553,7 @@ class Plan(object):
         self.fwd.set_ptr(self.in_op, 0, x.data_ptr())
         self.fwd.set_ptr(self.out_op, 1, hm.data_ptr())
         self.fwd.set_ptr(self.inter_op, 1, inter.data_ptr())
-        self.fwd.run()
+        self.fwd.run(streams=self._side_streams())
         return hm, inter
 
     def run_backward(self, g_hm, g_inter=None, segment_hook=None):
@@ -476,7 +562,7 @@ class Plan(object):
             # d(inter_feat) joins the gradient of stage3's branch-0 output before its consumers'
             # contributions are read: run up to that op, add it, continue
             cut = self.inter_gop
-            self.bwd.run(0, cut)
+            self.bwd.run(0, cut, streams=self._side_streams())
             ia = self.inter_act
             tmp = torch.empty(ia.N * ia.H * ia.W * ia.C * self.esize, dtype=torch.uint8, device=self.dev)
             C.call('hrnet_nchw_to_nhwc', self.dtid, g_inter.data_ptr(), tmp.data_ptr(), ia.N, ia.H, ia.W, ia.C,
@@ -488,14 +574,15 @@ class Plan(object):
             self._run_segments(0, len(self.bwd), segment_hook)
 
     def _run_segments(self, lo, hi, hook):
+        streams = self._side_streams()
         if hook is None:
-            self.bwd.run(lo, hi)
+            self.bwd.run(lo, hi, streams=streams)
             return
         cuts = [c for c in hook.cuts if lo < c < hi]
         prev = lo
         for c in cuts:
-            self.bwd.run(prev, c)
+            self.bwd.run(prev, c, streams=streams)
             hook.after(c)
             prev = c
-        self.bwd.run(prev, hi)
+        self.bwd.run(prev, hi, streams=streams)
         hook.after(hi)
