@@ -29,42 +29,79 @@ int hr_check_launch(const char* what) {
 extern "C" const char* hrnet_last_error_string(void) { return g_err; }
 extern "C" int hrnet_abi_version(void) { return 1; }
 
+static int run_one(const HrOp& op, hipStream_t s, int k) {
+  int e;
+  switch (op.kind) {
+    case HR_OP_CONV: e = hr_launch_conv(op, s); break;
+    case HR_OP_WGRAD: e = hr_launch_wgrad(op, s); break;
+    case HR_OP_WGRAD_REDUCE: e = hr_launch_wgrad_reduce(op, s); break;
+    case HR_OP_BN_FINALIZE: e = hr_launch_bn_finalize(op, s); break;
+    case HR_OP_SUM_TERMS: e = hr_launch_sum_terms(op, s); break;
+    case HR_OP_GRAD_TERM: e = hr_launch_grad_term(op, s); break;
+    case HR_OP_BN_BWD_REDUCE: e = hr_launch_bn_bwd_reduce(op, s); break;
+    case HR_OP_BN_BWD_FINALIZE: e = hr_launch_bn_bwd_finalize(op, s); break;
+    case HR_OP_BILINEAR_CAT: e = hr_launch_bilinear_cat(op, s); break;
+    case HR_OP_BILINEAR_CAT_BWD: e = hr_launch_bilinear_cat_bwd(op, s); break;
+    case HR_OP_IM2COL_STEM: e = hr_launch_im2col_stem(op, s); break;
+    case HR_OP_NHWC_TO_NCHW: e = hr_launch_nhwc_to_nchw(op, s); break;
+    case HR_OP_NCHW_TO_NHWC: e = hr_launch_nchw_to_nhwc(op, s); break;
+    case HR_OP_PACK_WEIGHTS: e = hr_launch_pack_weights(op, s); break;
+    case HR_OP_BIAS_GRAD: e = hr_launch_bias_grad(op, s); break;
+    case HR_OP_FILL: e = hr_launch_fill(op, s); break;
+    case HR_OP_PACK_TABLE: e = hr_launch_pack_table(op, s); break;
+    case HR_OP_EVENT_RECORD:
+      e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
+      if (e) hr_set_error("event record failed");
+      break;
+    case HR_OP_STREAM_WAIT:
+      e = hipStreamWaitEvent(s, (hipEvent_t)op.p[0], 0) == hipSuccess ? HR_OK : HR_E_LAUNCH;
+      if (e) hr_set_error("stream wait failed");
+      break;
+    default:
+      hr_set_error("program_run: unknown op kind %d at index %d", op.kind, k);
+      return HR_E_BADOP;
+  }
+  if (e != HR_OK) {
+    char tmp[400];
+    strncpy(tmp, g_err, sizeof(tmp) - 1);
+    tmp[sizeof(tmp) - 1] = 0;
+    hr_set_error("op %d (kind %d): %s", k, op.kind, tmp);
+  }
+  return e;
+}
+
 extern "C" int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
   for (int k = 0; k < n; ++k) {
-    const HrOp& op = ops[k];
-    int e;
-    switch (op.kind) {
-      case HR_OP_CONV: e = hr_launch_conv(op, s); break;
-      case HR_OP_WGRAD: e = hr_launch_wgrad(op, s); break;
-      case HR_OP_WGRAD_REDUCE: e = hr_launch_wgrad_reduce(op, s); break;
-      case HR_OP_BN_FINALIZE: e = hr_launch_bn_finalize(op, s); break;
-      case HR_OP_SUM_TERMS: e = hr_launch_sum_terms(op, s); break;
-      case HR_OP_GRAD_TERM: e = hr_launch_grad_term(op, s); break;
-      case HR_OP_BN_BWD_REDUCE: e = hr_launch_bn_bwd_reduce(op, s); break;
-      case HR_OP_BN_BWD_FINALIZE: e = hr_launch_bn_bwd_finalize(op, s); break;
-      case HR_OP_BILINEAR_CAT: e = hr_launch_bilinear_cat(op, s); break;
-      case HR_OP_BILINEAR_CAT_BWD: e = hr_launch_bilinear_cat_bwd(op, s); break;
-      case HR_OP_IM2COL_STEM: e = hr_launch_im2col_stem(op, s); break;
-      case HR_OP_NHWC_TO_NCHW: e = hr_launch_nhwc_to_nchw(op, s); break;
-      case HR_OP_NCHW_TO_NHWC: e = hr_launch_nchw_to_nhwc(op, s); break;
-      case HR_OP_PACK_WEIGHTS: e = hr_launch_pack_weights(op, s); break;
-      case HR_OP_BIAS_GRAD: e = hr_launch_bias_grad(op, s); break;
-      case HR_OP_FILL: e = hr_launch_fill(op, s); break;
-      case HR_OP_PACK_TABLE: e = hr_launch_pack_table(op, s); break;
-      default:
-        hr_set_error("program_run: unknown op kind %d at index %d", op.kind, k);
-        return HR_E_BADOP;
-    }
-    if (e != HR_OK) {
-      char tmp[400];
-      strncpy(tmp, g_err, sizeof(tmp) - 1);
-      tmp[sizeof(tmp) - 1] = 0;
-      hr_set_error("op %d (kind %d): %s", k, op.kind, tmp);
-      return e;
-    }
+    // single-stream execution is already ordered: lane markers are no-ops
+    if (ops[k].kind == HR_OP_EVENT_RECORD || ops[k].kind == HR_OP_STREAM_WAIT) continue;
+    const int e = run_one(ops[k], (hipStream_t)stream, k);
+    if (e != HR_OK) return e;
   }
   return HR_OK;
+}
+
+extern "C" int hrnet_program_run_streams(const HrOp* ops, int n, const hr_stream_t* streams, int nstreams) {
+  HR_REQUIRE(streams && nstreams >= 1, "program_run_streams: no streams");
+  for (int k = 0; k < n; ++k) {
+    const int lane = ops[k].i[HR_LANE_SLOT];
+    HR_REQUIRE(lane >= 0 && lane < nstreams, "program_run_streams: op %d lane %d out of range", k, lane);
+    const int e = run_one(ops[k], (hipStream_t)streams[lane], k);
+    if (e != HR_OK) return e;
+  }
+  return HR_OK;
+}
+
+extern "C" void* hrnet_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    hr_set_error("hipEventCreate failed");
+    return nullptr;
+  }
+  return (void*)ev;
+}
+
+extern "C" int hrnet_event_destroy(void* event) {
+  return hipEventDestroy((hipEvent_t)event) == hipSuccess ? HR_OK : HR_E_LAUNCH;
 }
 
 #define OP_BEGIN(KIND) \

@@ -22,7 +22,8 @@ class HrOp(ctypes.Structure):
                 ('p', ctypes.c_void_p * 14)]
 
 
-OP_PACK_TABLE = 17
+OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT = 17, 18, 19
+LANE_SLOT = 18
 
 
 class HrPackEnt(ctypes.Structure):
@@ -39,6 +40,8 @@ _ip = ctypes.POINTER(ctypes.c_int)
 _SIGS = {
     'hrnet_abi_version': [],
     'hrnet_program_run': [ctypes.POINTER(HrOp), _c_int, _c_vp],
+    'hrnet_program_run_streams': [ctypes.POINTER(HrOp), _c_int, _pp, _c_int],
+    'hrnet_event_destroy': [_c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_kernel_name': [_c_int] * 8 + [ctypes.c_char_p, _c_int],
@@ -75,7 +78,7 @@ _SIGS = {
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name'}
-EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string'])
+EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 
 _lib = None
 
@@ -95,6 +98,8 @@ def lib():
             fn.restype = ctypes.c_int
         l.hrnet_last_error_string.argtypes = []
         l.hrnet_last_error_string.restype = ctypes.c_char_p
+        l.hrnet_event_create.argtypes = []
+        l.hrnet_event_create.restype = ctypes.c_void_p
         _lib = l
     return _lib
 

@@ -77,20 +77,19 @@ class ConvRec(object):
 
 
 class Program(object):
-    """A recorded list of HrOp. Ops carry a lane; between a 'fork' and a 'join' marker the lanes are
-    independent chains (the branches of one HighResolutionModule) and run on separate HIP streams,
-    so the latency-bound low-resolution convolutions overlap the bandwidth-bound high-resolution
-    ones. Without side streams everything runs in order on the current stream (one C call)."""
+    """A recorded list of HrOp, run with ONE C call. Every op carries a lane (= stream index);
+    EVENT_RECORD / STREAM_WAIT ops express the dependencies between lanes: the branches of a
+    HighResolutionModule are independent chains, and weight-gradient work is off the backward
+    critical path, so the latency-bound kernels of one lane fill the gaps of another. On a single
+    stream (no side streams given) the same list runs in order and the event ops are skipped."""
 
     def __init__(self):
         self.ops = []
-        self.lanes = []
-        self.marks = []      # (position, 'fork'|'join', lanes)
         self.lane = 0
+        self.events = []
         self._arr = None
-        self._segs = None
 
-    def add(self, kind, ints=(), floats=(), ptrs=()):
+    def add(self, kind, ints=(), floats=(), ptrs=(), lane=None):
         op = C.HrOp()
         op.kind = kind
         for k, v in enumerate(ints):
@@ -99,31 +98,33 @@ class Program(object):
             op.f[k] = float(v)
         for k, v in enumerate(ptrs):
             op.p[k] = v
+        op.i[C.LANE_SLOT] = self.lane if lane is None else lane
         self.ops.append(op)
-        self.lanes.append(self.lane)
         self._arr = None
         return len(self.ops) - 1
 
-    def mark(self, what, lanes):
-        self.marks.append((len(self.ops), what, tuple(lanes)))
+    def lane_of(self, idx):
+        return self.ops[idx].i[C.LANE_SLOT]
+
+    def sync(self, src, dst):
+        """everything enqueued so far on lane `src` happens before what follows on lane `dst`"""
+        ev = C.lib().hrnet_event_create()
+        if not ev:
+            raise RuntimeError('hrnet_event_create failed')
+        self.events.append(ev)
+        self.add(C.OP_EVENT_RECORD, ptrs=(ev,), lane=src)
+        self.add(C.OP_STREAM_WAIT, ptrs=(ev,), lane=dst)
+
+    def fork(self, lanes):
+        for l in lanes:
+            self.sync(0, l)
+
+    def join(self, lanes):
+        for l in lanes:
+            self.sync(l, 0)
 
     def finalize(self):
         self._arr = (C.HrOp * len(self.ops))(*self.ops) if self.ops else None
-        segs, marks, mi, lo = [], sorted(self.marks, key=lambda m: m[0]), 0, 0
-        n = len(self.ops)
-        for i in range(n + 1):
-            while mi < len(marks) and marks[mi][0] == i:
-                if lo < i:
-                    segs.append(('run', lo, i, self.lanes[lo]))
-                    lo = i
-                segs.append((marks[mi][1], i, i, marks[mi][2]))
-                mi += 1
-            if i < n and i > lo and self.lanes[i] != self.lanes[lo]:
-                segs.append(('run', lo, i, self.lanes[lo]))
-                lo = i
-        if lo < n:
-            segs.append(('run', lo, n, self.lanes[lo]))
-        self._segs = segs
         return self
 
     def set_ptr(self, op_index, slot, value):
@@ -132,38 +133,26 @@ class Program(object):
     def set_int(self, op_index, slot, value):
         self._arr[op_index].i[slot] = value
 
-    def _call(self, lo, hi, stream_handle):
-        base = ctypes.cast(ctypes.byref(self._arr, lo * ctypes.sizeof(C.HrOp)), ctypes.POINTER(C.HrOp))
-        C.call('hrnet_program_run', base, hi - lo, stream_handle)
-
     def run(self, lo=0, hi=None, streams=None):
-        if self._segs is None:
+        if self._arr is None:
             self.finalize()
-        n = len(self.ops)
-        hi = n if hi is None else hi
+        hi = len(self.ops) if hi is None else hi
         if hi <= lo:
             return
-        if streams is None or not self.marks:
-            self._call(lo, hi, C.stream_ptr())
-            return
-        main = torch.cuda.current_stream()
-        for what, a, b, arg in self._segs:
-            if what == 'run':
-                a2, b2 = max(a, lo), min(b, hi)
-                if a2 < b2:
-                    st = main if arg == 0 else streams[arg]
-                    self._call(a2, b2, st.cuda_stream)
-            elif lo <= a < hi or (a == hi == n):
-                if what == 'fork':
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    for l in arg:
-                        streams[l].wait_event(ev)
-                else:
-                    for l in arg:
-                        ev = torch.cuda.Event()
-                        ev.record(streams[l])
-                        main.wait_event(ev)
+        base = ctypes.cast(ctypes.byref(self._arr, lo * ctypes.sizeof(C.HrOp)), ctypes.POINTER(C.HrOp))
+        if streams is None:
+            C.call('hrnet_program_run', base, hi - lo, C.stream_ptr())
+        else:
+            handles = (ctypes.c_void_p * len(streams))(
+                *[C.stream_ptr() if st is None else st.cuda_stream for st in streams])
+            C.call('hrnet_program_run_streams', base, hi - lo, handles, len(streams))
+
+    def __del__(self):
+        try:
+            for ev in self.events:
+                C.lib().hrnet_event_destroy(ev)
+        except Exception:
+            pass
 
     def __len__(self):
         return len(self.ops)
@@ -193,7 +182,8 @@ class Plan(object):
         self.pending = []         # (program, op_index, slot, kind) scratch pointers to patch
         self.bucket_marks = []    # backward op indices after which a gradient bucket is complete
         self.tape_lanes = []
-        self.nlanes = 4 if os.environ.get('HRNET_LANES', '1') != '0' else 1
+        self.nlanes = 4 if os.environ.get('HRNET_LANES', '1') != '0' else 1   # module branches
+        self.wlane = 4 if (self.nlanes > 1 and os.environ.get('HRNET_WLANE', '0') == '1') else 0   # weight-gradient lane
         self.streams = None
         self._build()
 
@@ -349,6 +339,8 @@ class Plan(object):
                                      ptrs=(C.ptr(inter.act.t), None))
         if self.need_grad:
             self._build_backward()
+            if self.wlane:
+                self.bwd.sync(self.wlane, 0)     # all weight gradients done before the optimiser
         self._resolve_scratch()
         self.fwd.finalize()
         self.bwd.finalize()
@@ -360,7 +352,7 @@ class Plan(object):
         xs = list(xs)
         side = [i for i in range(1, nb) if i < self.nlanes]
         if side:
-            self.fwd.mark('fork', side)
+            self.fwd.fork(side)
             self._tape(('fork', side))
         for i in range(nb):
             self.fwd.lane = i if i in side else 0
@@ -371,7 +363,7 @@ class Plan(object):
                 xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
         self.fwd.lane = 0
         if side:
-            self.fwd.mark('join', side)
+            self.fwd.join(side)
             self._tape(('join', side))
         outs = []
         for i in range(nb):
@@ -443,7 +435,10 @@ class Plan(object):
             if e[0] in ('fork', 'join'):
                 # a forward join is the backward fork of the same lanes, and vice versa
                 self.bwd.lane = 0
-                self.bwd.mark('fork' if e[0] == 'join' else 'join', e[1])
+                if e[0] == 'join':
+                    self.bwd.fork(e[1])
+                else:
+                    self.bwd.join(e[1])
                 in_region = e[0] == 'join'
                 continue
             if e[0] == 'cat':
@@ -502,6 +497,10 @@ class Plan(object):
                     i = self.bwd.add(C.OP_BIAS_GRAD, ints=(self.dtid, y.pixels, y.C, crec.Cout, 1),
                                      ptrs=(C.ptr(y.g), C.ptr(net.grad_of(crec.mod.bias)), None))
                     self._scratch(self.bwd, i, 2, 'bwdpart')
+                # the weight gradient is off the critical path: it runs on its own lane once dY is final
+                if self.wlane:
+                    self.bwd.sync(lane, self.wlane)
+                    self.bwd.lane = self.wlane
                 nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
                 self.max_slab = max(self.max_slab, nsplit * y.C * ks * ks * x.C)
                 i = self.bwd.add(C.OP_WGRAD,
@@ -516,6 +515,7 @@ class Plan(object):
                 self._scratch(self.bwd, i, 0, 'slab')
                 if crec.stem:
                     self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
+                self.bwd.lane = lane
                 if x.g is not None:
                     # input gradient = conv of dY with the transposed kernel (zero-stuffed for stride 2)
                     self.bwd.add(C.OP_CONV,
@@ -524,13 +524,15 @@ class Plan(object):
                                  ptrs=(C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None))
                     x.ginit = True
                 if lane == 0 and not in_region:
+                    if self.wlane:
+                        self.bwd.sync(self.wlane, 0)    # this bucket's weight gradients are complete
                     self.bucket_marks.append((len(self.bwd), crec.prefix))
 
     def _resolve_scratch(self):
         sizes = {'stats': max(self.max_stats, 1), 'slab': max(self.max_slab, 1), 'bwdpart': max(self.max_bwd_part, 1)}
         table = {}
         for prog, idx, slot, kind in self.pending:
-            key = (kind, prog.lanes[idx])      # concurrent lanes must not share scratch
+            key = (kind, prog.lane_of(idx))    # concurrent lanes must not share scratch
             if key not in table:
                 table[key] = self._f32(sizes[kind])
             prog.ops[idx].p[slot] = C.ptr(table[key])
@@ -541,7 +543,10 @@ class Plan(object):
         if self.nlanes <= 1:
             return None
         if self.streams is None:
-            self.streams = [None] + [torch.cuda.Stream(device=self.dev) for _ in range(self.nlanes - 1)]
+            # lane 0 = PyTorch's current stream. (Measured on MI355X: high-priority side streams made the
+            # backward 2.5x slower, and a separate weight-gradient lane 7 % slower - its big grids take
+            # CU slots from the critical path - so both stay off by default.)
+            self.streams = [None] + [torch.cuda.Stream(device=self.dev) for _ in range(self.nlanes)]
         return self.streams
 
     # ---- execution --------------------------------------------------------------------------

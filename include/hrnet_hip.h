@@ -57,7 +57,9 @@ enum {
   HR_OP_PACK_WEIGHTS = 14,
   HR_OP_BIAS_GRAD = 15,
   HR_OP_FILL = 16,
-  HR_OP_PACK_TABLE = 17
+  HR_OP_PACK_TABLE = 17,
+  HR_OP_EVENT_RECORD = 18, /* p[0] = event, recorded on the op's lane */
+  HR_OP_STREAM_WAIT = 19   /* p[0] = event, the op's lane waits for it */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -74,6 +76,14 @@ int hrnet_abi_version(void);
 
 /* Run `n` recorded ops in order on `stream` (one host call per forward / backward pass). */
 int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream);
+/* The same over several streams: op.i[HR_LANE_SLOT] selects streams[lane]; HR_OP_EVENT_RECORD /
+ * HR_OP_STREAM_WAIT ops express the dependencies between lanes (independent branches of a
+ * HighResolutionModule, weight-gradient work off the critical path). Events come from
+ * hrnet_event_create (host-side handles; no device memory). */
+#define HR_LANE_SLOT 18
+int hrnet_program_run_streams(const HrOp* ops, int n, const hr_stream_t* streams, int nstreams);
+void* hrnet_event_create(void);
+int hrnet_event_destroy(void* event);
 
 /*
  * Convolution as implicit GEMM on MFMA. Replaces nn.Conv2d forward (pose_hrnet.py:22-25,
