@@ -269,9 +269,9 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   const int gz = (Cin + c.kc - 1) / c.kc;
   // ~1000 workgroups (4 per CU: the kernel has no software pipelining, occupancy hides its latency);
   // each split costs one f32 slab of Cout*taps*Cin written and re-read by hrnet_wgrad_reduce
-  int ns = 1024 / (gy * gz);
+  int ns = 768 / (gy * gz);
   if (ns < 1) ns = 1;
-  if (ns > 256) ns = 256;
+  if (ns > 128) ns = 128;
   if (ns > tiles) ns = tiles;
   return ns;
 }
