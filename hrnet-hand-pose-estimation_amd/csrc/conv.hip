@@ -18,6 +18,8 @@
 // across waves, one row per workgroup to HBM (deterministic; finished by bn_finalize).
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -120,18 +122,47 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   unsigned xok = 0;
   float sc[VEC], sh[VEC];
 
-  auto tile_coords = [&](int t, int& n, int& ty, int& tx) {
-    int b = tile0 + t;
-    tx = b % a.tiles_x;
-    b /= a.tiles_x;
-    ty = b % a.tiles_y;
-    n = b / a.tiles_y;
+  // Per-thread staging geometry is the same for every tile: halo coordinates, the byte offset of
+  // the element relative to the tile's first halo pixel, and its LDS slot are computed ONCE; per
+  // tile only two adds + two unsigned compares per element remain (the address is a wave-uniform
+  // base + a constant per-lane offset).
+  const int esz = (int)sizeof(T);
+  const int rowB = a.W * a.Cin * esz;      // bytes per stored input row
+  const int pixB = a.Cin * esz;
+  int hyx[C::XV], goff[C::XV];
+#pragma unroll
+  for (int k = 0; k < C::XV; ++k) {
+    const int pix = (tid + k * 256) / C::VPP;
+    const int hy = pix / C::HALO_W, hx = pix % C::HALO_W;
+    hyx[k] = (hy << 16) | hx;
+    goff[k] = a.upz ? 0 : hy * rowB + hx * pixB + v * 16;
+  }
+  const int ldsx = (tid / C::VPP) * C::PIXB + v * 16;   // + k * (256 / VPP) * PIXB
+
+  // tile walk without divisions inside the loop
+  int cur_n, cur_ty, cur_tx;      // tile whose loads are being issued
+  {
+    int bq = tile0;
+    cur_tx = bq % a.tiles_x;
+    bq /= a.tiles_x;
+    cur_ty = bq % a.tiles_y;
+    cur_n = bq / a.tiles_y;
+  }
+  int ep_n = cur_n, ep_ty = cur_ty, ep_tx = cur_tx;   // tile whose accumulators are being finished
+  auto advance = [&](int& n, int& ty, int& tx) {
+    if (++tx == a.tiles_x) {
+      tx = 0;
+      if (++ty == a.tiles_y) {
+        ty = 0;
+        ++n;
+      }
+    }
   };
 
   auto load_stage = [&](int s) {
     const int t = s / nch, ch = s - t * nch;
-    int n, ty, tx;
-    tile_coords(t, n, ty, tx);
+    const int n = __builtin_amdgcn_readfirstlane(cur_n), ty = __builtin_amdgcn_readfirstlane(cur_ty),
+              tx = __builtin_amdgcn_readfirstlane(cur_tx);
     const int iy0 = ty * TH * STRIDE - PAD, ix0 = tx * TW * STRIDE - PAD;
     const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
@@ -143,26 +174,37 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       }
     }
     xok = 0;
+    if (!a.upz) {
+      // wave-uniform base of (image n, halo origin, channel chunk); may point before the image
+      const char* base = a.x + (size_t)n * a.H * rowB + (ptrdiff_t)iy0 * rowB + (ptrdiff_t)ix0 * pixB +
+                         ch * C::KC * esz;
 #pragma unroll
-    for (int k = 0; k < C::XV; ++k) {
-      const int idx = tid + k * 256;
-      const int pix = idx / C::VPP;
-      const int hy = pix / C::HALO_W, hx = pix % C::HALO_W;
-      const int gy = iy0 + hy, gx = ix0 + hx;
-      bool ok = idx < C::XVECS && cvalid && gy >= 0 && gy < a.Hz && gx >= 0 && gx < a.Wz;
-      int sy = gy, sx = gx;
-      if (a.upz) {
-        ok = ok && !((gy | gx) & 1);
-        sy = gy >> 1;
-        sx = gx >> 1;
-        ok = ok && sy < a.H && sx < a.W;
+      for (int k = 0; k < C::XV; ++k) {
+        const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
+        const bool ok = (tid + k * 256) < C::XVECS && cvalid && (unsigned)gy < (unsigned)a.Hz &&
+                        (unsigned)gx < (unsigned)a.Wz;
+        xr[k] = v16_zero();
+        if (ok) {
+          xr[k] = *(const V16*)(base + goff[k]);
+          xok |= 1u << k;
+        }
       }
-      xr[k] = v16_zero();
-      if (ok) {
-        xr[k] = *(const V16*)(a.x + ((size_t)((n * a.H + sy) * a.W + sx) * a.Cin + c) * sizeof(T));
-        xok |= 1u << k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::XV; ++k) {
+        const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
+        bool ok = (tid + k * 256) < C::XVECS && cvalid && (unsigned)gy < (unsigned)a.Hz &&
+                  (unsigned)gx < (unsigned)a.Wz && !((gy | gx) & 1);
+        const int sy = gy >> 1, sx = gx >> 1;
+        ok = ok && sy < a.H && sx < a.W;
+        xr[k] = v16_zero();
+        if (ok) {
+          xr[k] = *(const V16*)(a.x + ((size_t)((n * a.H + sy) * a.W + sx) * a.Cin + c) * sizeof(T));
+          xok |= 1u << k;
+        }
       }
     }
+    if (ch == nch - 1) advance(cur_n, cur_ty, cur_tx);
     if (!wres || s == 0) {
 #pragma unroll
       for (int k = 0; k < C::WV; ++k) {
@@ -177,25 +219,36 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
   };
 
-  auto store_stage = [&](int s) {
+  // BatchNorm affine (+ReLU) of the staged vectors; the three variants are selected by ONE
+  // wave-uniform branch (runtime flags inside the unrolled loop made the compiler evaluate both
+  // sides and select per element: 56 VALU per vector instead of 28)
+  auto xform = [&](auto aff_tag, auto relu_tag) {
+    constexpr bool AFF = decltype(aff_tag)::value, RELU = decltype(relu_tag)::value;
 #pragma unroll
     for (int k = 0; k < C::XV; ++k) {
-      const int idx = tid + k * 256;
-      if (idx < C::XVECS) {
-        V16 val = xr[k];
-        if (((xok >> k) & 1u) && (has_affine || a.in_relu)) {
-          float f[VEC];
-          v16_unpack<T>(val, f);
+      if ((xok >> k) & 1u) {
+        float f[VEC];
+        v16_unpack<T>(xr[k], f);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
-            if (a.in_relu) f[j] = fmaxf(f[j], 0.f);
-          }
-          val = v16_pack<T>(f);
+        for (int j = 0; j < VEC; ++j) {
+          if constexpr (AFF) f[j] = fmaf(f[j], sc[j], sh[j]);
+          if constexpr (RELU) f[j] = f[j] > 0.f ? f[j] : 0.f;
         }
-        *(V16*)(xl + (idx / C::VPP) * C::PIXB + v * 16) = val;
+        xr[k] = v16_pack<T>(f);
       }
     }
+  };
+
+  auto store_stage = [&](int s) {
+    if (has_affine) {
+      if (a.in_relu) xform(std::true_type{}, std::true_type{});
+      else xform(std::true_type{}, std::false_type{});
+    } else if (a.in_relu) {
+      xform(std::false_type{}, std::true_type{});
+    }
+#pragma unroll
+    for (int k = 0; k < C::XV; ++k)
+      if (tid + k * 256 < C::XVECS) *(V16*)(xl + ldsx + k * (256 / C::VPP) * C::PIXB) = xr[k];
     if (!wres || s == 0) {
 #pragma unroll
       for (int k = 0; k < C::WV; ++k) {
@@ -219,11 +272,22 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < C::LANE_C; ++k) s1[k] = s2[k] = 0.f;
 
+#ifdef HR_STAMP
+  unsigned long long* stamp_buf = (unsigned long long*)a.stats + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32;
+  int stamp_i = 0;
+#define STAMP() do { if (tid == 0 && stamp_i < 32) stamp_buf[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+  STAMP();
   if (nstage > 0) load_stage(0);
+  STAMP();
   for (int s = 0; s < nstage; ++s) {
     const int t = s / nch, ch = s - t * nch;
     store_stage(s);
+    STAMP();
     __syncthreads();
+    STAMP();
     if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
     if (ch == 0) {
 #pragma unroll
@@ -249,10 +313,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
           for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
       }
     }
+    STAMP();
     if (ch == nch - 1) {
       // ---- tile epilogue: bias, (accumulate), 4*FC contiguous couts per pixel, BN statistics ----
-      int n, ty, tx;
-      tile_coords(t, n, ty, tx);
+      const int n = __builtin_amdgcn_readfirstlane(ep_n), ty = __builtin_amdgcn_readfirstlane(ep_ty),
+                tx = __builtin_amdgcn_readfirstlane(ep_tx);
+      advance(ep_n, ep_ty, ep_tx);
 #pragma unroll
       for (int fp = 0; fp < C::FP; ++fp) {
         const int p = wp * C::PM + fp * 16 + li;
@@ -296,10 +362,16 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         }
       }
     }
+    STAMP();
     __syncthreads();  // every wave is done reading this stage's LDS image
+    STAMP();
   }
 
+#ifdef HR_STAMP
+  if (false) {
+#else
   if (a.stats) {
+#endif
     float* sl = (float*)lds;  // [WP][2][BN] (the loop ended on a barrier: LDS is free)
 #pragma unroll
     for (int k = 0; k < C::LANE_C; ++k) {
