@@ -69,13 +69,31 @@ def conv_flops_table(plan):
     for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
         for idx, op in enumerate(prog.ops):
             if op.kind == C.OP_CONV:
-                C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
-                       op.i[10], buf, 160)
+                C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[4], op.i[7], op.i[8],
+                       op.i[9], op.i[10], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, False))
             elif op.kind == C.OP_WGRAD:
                 C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, True))
     return out
+
+
+def traffic_of(kernel_name):
+    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/traffic_rNN.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by
+    scratch/pmc_traffic.py); None if the table has no row for it."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'traffic_r*.json')))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))
+    m = re.match(r'(conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
+    if not m:
+        return None
+    key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])
+    row = table.get(key)
+    return row['hbm_bytes_per_launch'] if row else None
 
 
 def instrumented_step(model, x, gt, criterion):
@@ -237,7 +255,7 @@ def main():
         name, (n, ms, fl) = dom
         ach = fl / (ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 5), 'traffic': None, 'kernel': name, 'launches_per_step': n,
+                'frac': round(ach / peak, 5), 'traffic': traffic_of(name), 'kernel': name, 'launches_per_step': n,
                 'avg_launch_us': round(ms / n * 1e3, 2)}
         mfma_ms = sum(v[1] for v in stats.values())
         mfma_fl = sum(v[2] for v in stats.values())

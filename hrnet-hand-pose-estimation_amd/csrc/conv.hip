@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   int aoff[C::FC];
 #pragma unroll
   for (int fc = 0; fc < C::FC; ++fc) {
-    const int row = wc * C::CN + (li >> 2) * C::LANE_C + fc * 4 + (li & 3);
+    // weight rows are STORED in MFMA order (row q = fc*16 + li of the wave's block holds output channel
+    // (li>>2)*LANE_C + fc*4 + (li&3)), so the 16 lanes of a fragment read 16 consecutive padded rows:
+    // conflict-free, where reading permuted rows put rows r and r+16 on the same banks
+    const int row = wc * C::CN + fc * 16 + li;
     aoff[fc] = row * C::WROWB + lg * 16;
   }
   int boff[C::FP];
@@ -211,7 +214,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         const int idx = tid + k * 256;
         const int rt = idx / C::VPP;
         const int tp = rt % C::TAPS, r = rt / C::TAPS;
-        const int co = n0 + r;
+        const int q = r % C::CN;   // LDS row r holds the output channel the MFMA row order needs
+        const int co = n0 + (r / C::CN) * C::CN + ((q & 15) >> 2) * C::LANE_C + (q >> 4) * 4 + (q & 3);
         wr[k] = v16_zero();
         if (idx < C::WVECS && cvalid && co < a.Cout)
           wr[k] = *(const V16*)(a.w + ((size_t)(co * C::TAPS + tp) * a.Cin + c) * sizeof(T));
@@ -262,7 +266,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
   };
 
-  f32x4 acc[C::FC][C::FP];
   const int cbase = n0 + wc * C::CN + lg * C::LANE_C;
   const bool cok = cbase < a.Cout;
   float bias[C::LANE_C];
@@ -282,88 +285,96 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   STAMP();
   if (nstage > 0) load_stage(0);
   STAMP();
-  for (int s = 0; s < nstage; ++s) {
-    const int t = s / nch, ch = s - t * nch;
-    store_stage(s);
-    STAMP();
-    __syncthreads();
-    STAMP();
-    if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
-    if (ch == 0) {
+  // tile loop outside, K-chunk loop inside: the accumulators live in one tile iteration (declared,
+  // zeroed, accumulated in place, stored). A flat stage loop with a conditional reset made hipcc shuffle
+  // every accumulator AGPR<->VGPR around each MFMA (12-16 v_accvgpr moves per MFMA).
+  int s = 0;
+  for (int t = 0; t < ntile; ++t) {
+    f32x4 acc[C::FC][C::FP];
 #pragma unroll
-      for (int fc = 0; fc < C::FC; ++fc)
+    for (int fc = 0; fc < C::FC; ++fc)
 #pragma unroll
-        for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+      for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nch; ++ch, ++s) {
+      store_stage(s);
+      STAMP();
+      __syncthreads();
+      STAMP();
+      if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
 #pragma unroll
-    for (int tp = 0; tp < C::TAPS; ++tp) {
-      const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
+      for (int tp = 0; tp < C::TAPS; ++tp) {
+        const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
 #pragma unroll
-      for (int kk = 0; kk < KM; ++kk) {
-        constexpr int KB = C::KSTEP * (int)sizeof(T);   // bytes of one fragment step
-        V16 af[C::FC], bf[C::FP];
+        for (int kk = 0; kk < KM; ++kk) {
+          constexpr int KB = C::KSTEP * (int)sizeof(T);   // bytes of one fragment step
+          V16 af[C::FC], bf[C::FP];
 #pragma unroll
-        for (int fc = 0; fc < C::FC; ++fc)
-          af[fc] = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
+          for (int fc = 0; fc < C::FC; ++fc)
+            af[fc] = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
 #pragma unroll
-        for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb + kk * KB);
+          for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb + kk * KB);
 #pragma unroll
-        for (int fc = 0; fc < C::FC; ++fc)
+          for (int fc = 0; fc < C::FC; ++fc)
 #pragma unroll
-          for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
+            for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
+        }
+      }
+      STAMP();
+      if (ch + 1 < nch) {
+        __syncthreads();  // every wave is done reading this chunk's LDS image
+        STAMP();
       }
     }
-    STAMP();
-    if (ch == nch - 1) {
-      // ---- tile epilogue: bias, (accumulate), 4*FC contiguous couts per pixel, BN statistics ----
-      const int n = __builtin_amdgcn_readfirstlane(ep_n), ty = __builtin_amdgcn_readfirstlane(ep_ty),
-                tx = __builtin_amdgcn_readfirstlane(ep_tx);
-      advance(ep_n, ep_ty, ep_tx);
+    {
+    // ---- tile epilogue: bias, (accumulate), 4*FC contiguous couts per pixel, BN statistics ----
+    const int n = __builtin_amdgcn_readfirstlane(ep_n), ty = __builtin_amdgcn_readfirstlane(ep_ty),
+              tx = __builtin_amdgcn_readfirstlane(ep_tx);
+    advance(ep_n, ep_ty, ep_tx);
 #pragma unroll
-      for (int fp = 0; fp < C::FP; ++fp) {
-        const int p = wp * C::PM + fp * 16 + li;
-        const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
-        const bool pok = cok && oy < a.Ho && ox < a.Wo;
-        float vals[C::LANE_C];
+    for (int fp = 0; fp < C::FP; ++fp) {
+      const int p = wp * C::PM + fp * 16 + li;
+      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      const bool pok = cok && oy < a.Ho && ox < a.Wo;
+      float vals[C::LANE_C];
 #pragma unroll
-        for (int fc = 0; fc < C::FC; ++fc) {
-          vals[fc * 4 + 0] = acc[fc][fp].x + bias[fc * 4 + 0];
-          vals[fc * 4 + 1] = acc[fc][fp].y + bias[fc * 4 + 1];
-          vals[fc * 4 + 2] = acc[fc][fp].z + bias[fc * 4 + 2];
-          vals[fc * 4 + 3] = acc[fc][fp].w + bias[fc * 4 + 3];
+      for (int fc = 0; fc < C::FC; ++fc) {
+        vals[fc * 4 + 0] = acc[fc][fp].x + bias[fc * 4 + 0];
+        vals[fc * 4 + 1] = acc[fc][fp].y + bias[fc * 4 + 1];
+        vals[fc * 4 + 2] = acc[fc][fp].z + bias[fc * 4 + 2];
+        vals[fc * 4 + 3] = acc[fc][fp].w + bias[fc * 4 + 3];
+      }
+      if (pok) {
+        char* dst = a.y + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
+#pragma unroll
+        for (int k = 0; k < C::LANE_C; ++k) {
+          s1[k] += vals[k];
+          s2[k] += vals[k] * vals[k];
         }
-        if (pok) {
-          char* dst = a.y + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
 #pragma unroll
-          for (int k = 0; k < C::LANE_C; ++k) {
-            s1[k] += vals[k];
-            s2[k] += vals[k] * vals[k];
-          }
+        for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
+          if constexpr (C::LANE_C >= VEC) {
+            if (a.accumulate) {
+              float old[VEC];
+              v16_unpack<T>(*(const V16*)(dst + k0 * sizeof(T)), old);
 #pragma unroll
-          for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
-            if constexpr (C::LANE_C >= VEC) {
-              if (a.accumulate) {
-                float old[VEC];
-                v16_unpack<T>(*(const V16*)(dst + k0 * sizeof(T)), old);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) vals[k0 + j] += old[j];
-              }
-              *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
-            } else {
-              // LANE_C == 4 with bf16: one 8-byte store
-              if (a.accumulate) {
-                const bf16x4 old = *(const bf16x4*)dst;
-                vals[0] += (float)old.x; vals[1] += (float)old.y; vals[2] += (float)old.z; vals[3] += (float)old.w;
-              }
-              const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
-              *(bf16x4*)dst = o;
+              for (int j = 0; j < VEC; ++j) vals[k0 + j] += old[j];
             }
+            *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
+          } else {
+            // LANE_C == 4 with bf16: one 8-byte store
+            if (a.accumulate) {
+              const bf16x4 old = *(const bf16x4*)dst;
+              vals[0] += (float)old.x; vals[1] += (float)old.y; vals[2] += (float)old.z; vals[3] += (float)old.w;
+            }
+            const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
+            *(bf16x4*)dst = o;
           }
         }
       }
     }
+    }
     STAMP();
-    __syncthreads();  // every wave is done reading this stage's LDS image
+    __syncthreads();  // the last chunk's LDS image is free again
     STAMP();
   }
 
@@ -404,10 +415,12 @@ struct TileChoice {
 };
 
 TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride) {
-  // id: 0 = 16x16/BN32 (4x1 waves), 1 = 8x16/BN64 (2x2), 2 = 8x8/BN64 (2x2), 3 = 8x8/BN32 (2x2)
+  // id: 0 = 16x16/BN32 (4x1 waves), 1 = 8x16/BN64 (2x2), 2 = 8x8/BN64 (2x2), 3 = 8x8/BN32 (2x2),
+  //     4 = 8x16/BN128 (2x2; 1x1 convs with many output channels: 64 FLOP per staged byte)
   TileChoice tc;
   if (stride == 2) tc = Cout >= 64 ? TileChoice{8, 8, 64, 2, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
   else if (Cout <= 32) tc = (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
+  else if (ks == 1 && Cout >= 128 && Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 128, 4, 1, 0};  // GEMM-like
   else if (Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 64, 1, 1, 0};
   else tc = TileChoice{8, 8, 64, 2, 1, 0};
   const int tiles = N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
@@ -429,27 +442,48 @@ TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride) {
   return tc;
 }
 
-template <typename T, int KS, int STRIDE>
-int launch_cfg(const ConvArgs& a, const TileChoice& tc, int N, hipStream_t s) {
+// K depth per stage (fragment steps staged per barrier pair). A 1x1 conv has one tap, so it stages 4
+// steps (2 when Cin <= 2 steps: no zero-padded MFMAs); 8x8/BN32 3x3 tiles have LDS room for two.
+inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
+  const int kstep = dtype == HR_F32 ? 16 : 32;
+  if (ks == 1) return Cin <= 2 * kstep ? 2 : 4;
+  return tile_id == 3 ? 2 : 1;
+}
+
+template <typename T, int KS, int STRIDE, int KM>
+int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
   dim3 grid((unsigned)tc.gx, (unsigned)((a.Cout + tc.bn - 1) / tc.bn));
-  // K depth per stage: a 1x1 conv has one tap, so it stages 4 fragment steps per barrier pair
-  constexpr int KM1 = KS == 1 ? 4 : 1;
-  constexpr int KM3 = KS == 1 ? 4 : 2;   // 8x8 / BN32 tiles have LDS room for two steps
   switch (tc.id) {
-    case 0:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 16, 16, 32, 4, 1, KM1>), grid, dim3(256), 0, s, a);
+    case 0:   // (stride-2 convs only use the 8x8 tiles: their halo is (2*T+1)^2)
+      if constexpr (STRIDE == 1)
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 16, 16, 32, 4, 1, KM>), grid, dim3(256), 0, s, a);
       break;
     case 1:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 16, 64, 2, 2, KM1>), grid, dim3(256), 0, s, a);
+      if constexpr (STRIDE == 1)
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 16, 64, 2, 2, KM>), grid, dim3(256), 0, s, a);
       break;
     case 2:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 64, 2, 2, KM1>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 64, 2, 2, KM>), grid, dim3(256), 0, s, a);
+      break;
+    case 4:
+      if constexpr (KS == 1)
+        hipLaunchKernelGGL((conv_kernel<T, 1, 1, 8, 16, 128, 2, 2, KM>), grid, dim3(256), 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 32, 2, 2, KM3>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 32, 2, 2, KM>), grid, dim3(256), 0, s, a);
       break;
   }
   return hr_check_launch("conv2d");
+}
+
+template <typename T, int KS, int STRIDE>
+int launch_cfg(const ConvArgs& a, const TileChoice& tc, int N, hipStream_t s) {
+  const int km = conv_km(TT<T>::ID, KS, a.Cin, tc.id);
+  if constexpr (KS == 1) {
+    return km == 2 ? launch_km<T, 1, 1, 2>(a, tc, s) : launch_km<T, 1, 1, 4>(a, tc, s);
+  } else {
+    return km == 2 ? launch_km<T, KS, STRIDE, 2>(a, tc, s) : launch_km<T, KS, STRIDE, 1>(a, tc, s);
+  }
 }
 
 template <typename T>
@@ -526,12 +560,12 @@ extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float
 
 // Demangled-style name of the kernel instantiation hrnet_conv2d launches for this shape (so that
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
-extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cout, int ks, int stride, int upz,
-                                      char* buf, int buflen) {
+extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride,
+                                      int upz, char* buf, int buflen) {
   const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride);
-  static const int wp[4] = {4, 2, 2, 2}, wc[4] = {1, 2, 2, 2};
+  static const int wp[5] = {4, 2, 2, 2, 2}, wc[5] = {1, 2, 2, 2, 2};
   const int kstride = (ks == 1 || upz) ? 1 : stride;
-  const int km = ks == 1 ? 4 : (tc.id == 3 ? 2 : 1);
+  const int km = conv_km(dtype, ks, Cin, tc.id);
   return snprintf(buf, buflen, "conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",
                   ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
 }

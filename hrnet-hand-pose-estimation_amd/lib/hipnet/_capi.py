@@ -44,7 +44,7 @@ _SIGS = {
     'hrnet_event_destroy': [_c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
     'hrnet_conv_tiles': [_c_int] * 6,
-    'hrnet_conv_kernel_name': [_c_int] * 8 + [ctypes.c_char_p, _c_int],
+    'hrnet_conv_kernel_name': [_c_int] * 9 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
     'hrnet_wgrad_splits': [_c_int] * 8,

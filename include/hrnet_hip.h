@@ -106,7 +106,7 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                  int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int upz,
                  int in_relu, int accumulate, hr_stream_t stream);
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
-int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cout, int ks, int stride, int upz,
+int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,
                            char* buf, int buflen);
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */

@@ -5,7 +5,7 @@ import torch, numpy as np
 import hip_helpers as hh
 from hipnet import _capi as C
 dt = torch.bfloat16
-N, H, Cin = 64, int(sys.argv[1]), int(sys.argv[2]); Cout = Cin; ks = 3
+N, H, Cin = 64, int(sys.argv[1]), int(sys.argv[2]); Cout = Cin; ks = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 aff = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 x = torch.randn(N, H, H, Cin, device='cuda').to(dt)
 w = torch.randn(Cout, Cin, ks, ks) * 0.05
