@@ -1,0 +1,320 @@
+// Deformable convolution v1 (config 5 of BASELINE.json; reference lib/deformable_conv:
+// src/cuda/deform_im2col_cuda.cuh:24-53 bilinear rule, :127-189 sampling + offset channel order,
+// :192-310 gradients; src/cuda/deform_conv_cuda.cu:19-271 shapes / bias / groups).
+//
+//   out[b,o,y,x] = bias[o] + sum_{c,i,j} W[o,c,i,j] * sample(in[b,c], y*s-p+i*d+dy, x*s-p+j*d+dx)
+//
+// HBM / gather-bound: the offsets (2*kh*kw floats per deformable group and pixel) dominate the
+// bytes, the samples are L2-resident gathers and the 21x189 contraction is tiny - so the column
+// buffer of the reference (198 MB at B=64) is never materialised: one thread owns one output pixel,
+// streams its offsets once (coalesced along x), samples, and applies the weights straight from LDS
+// (wave-uniform broadcast reads). NCHW f32 like the reference op.
+#include "common.h"
+
+namespace {
+
+struct DcnArgs {
+  const float* in;    // [B,C,H,W]
+  const float* off;   // [B,DG*2*K,Ho,Wo]
+  const float* w;     // [Co,C/G,kh,kw]
+  const float* bias;  // [Co] or null
+  const float* gout;  // [B,Co,Ho,Wo]
+  float* out;         // [B,Co,Ho,Wo]
+  float* gin;         // [B,C,H,W]   (atomic accumulation: zeroed by the caller)
+  float* goff;        // [B,DG*2*K,Ho,Wo]
+  float* partial;     // [blocks][Og][Cg][K]
+  int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, DG;
+  int c0, Cg, o0, Og;  // this launch's conv group: input channels [c0,c0+Cg), outputs [o0,o0+Og)
+};
+
+// reference bilinear (deform_im2col_cuda.cuh:24-53): corners outside the image contribute 0
+__device__ __forceinline__ float dcn_sample(const float* plane, int H, int W, float h, float w) {
+  const int hl = (int)floorf(h), wl = (int)floorf(w);
+  const int hh_ = hl + 1, wh = wl + 1;
+  const float lh = h - hl, lw = w - wl, hh = 1.f - lh, hw = 1.f - lw;
+  const float v1 = (hl >= 0 && wl >= 0) ? plane[hl * W + wl] : 0.f;
+  const float v2 = (hl >= 0 && wh <= W - 1) ? plane[hl * W + wh] : 0.f;
+  const float v3 = (hh_ <= H - 1 && wl >= 0) ? plane[hh_ * W + wl] : 0.f;
+  const float v4 = (hh_ <= H - 1 && wh <= W - 1) ? plane[hh_ * W + wh] : 0.f;
+  return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
+__device__ __forceinline__ bool dcn_inside(float h, float w, int H, int W) {
+  return h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+}
+
+constexpr int OC = 32;  // output channels per thread pass
+
+__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int oc0, int ocn) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cg*K][OC], zero beyond ocn
+  const int K = a.kh * a.kw;
+  for (int i = threadIdx.x; i < OC * a.Cg * K; i += 256) {
+    const int o = i % OC, ck = i / OC;
+    wl[i] = o < ocn ? a.w[(size_t)(oc0 + o) * a.Cg * K + ck] : 0.f;
+  }
+  __syncthreads();
+  const long long npix = (long long)a.B * a.Ho * a.Wo;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix) return;
+  const int x = (int)(idx % a.Wo);
+  const int y = (int)((idx / a.Wo) % a.Ho);
+  const int b = (int)(idx / ((long long)a.Wo * a.Ho));
+  float acc[OC];
+#pragma unroll
+  for (int o = 0; o < OC; ++o) acc[o] = (a.bias && o < ocn) ? a.bias[oc0 + o] : 0.f;
+  const int cpd = a.C / a.DG;
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+  for (int cl = 0; cl < a.Cg; ++cl) {
+    const int c = a.c0 + cl;
+    const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
+    const float* offp = a.off + ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + (size_t)y * a.Wo + x;
+    for (int k = 0; k < K; ++k) {
+      const int i = k / a.kw, j = k % a.kw;
+      const float h = (float)(y * a.sh - a.ph + i * a.dh) + offp[(size_t)(2 * k) * plane_o];
+      const float w = (float)(x * a.sw - a.pw + j * a.dw) + offp[(size_t)(2 * k + 1) * plane_o];
+      const float val = dcn_inside(h, w, a.H, a.W) ? dcn_sample(plane, a.H, a.W, h, w) : 0.f;
+      const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OC);
+#pragma unroll
+      for (int o = 0; o < OC / 4; ++o) {
+        const float4 w4 = wk[o];
+        acc[4 * o] = fmaf(w4.x, val, acc[4 * o]);
+        acc[4 * o + 1] = fmaf(w4.y, val, acc[4 * o + 1]);
+        acc[4 * o + 2] = fmaf(w4.z, val, acc[4 * o + 2]);
+        acc[4 * o + 3] = fmaf(w4.w, val, acc[4 * o + 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < OC; ++o)
+    if (o < ocn) a.out[((size_t)b * a.Co + oc0 + o) * plane_o + (size_t)y * a.Wo + x] = acc[o];
+}
+
+// grad wrt input (atomics, as the reference's col2im) and wrt offsets (direct store: one thread owns
+// every (pixel, offset channel) of its deformable groups)
+template <int OCP>
+__global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cg*K][OCP], zero beyond Og
+  const int K = a.kh * a.kw;
+  for (int i = threadIdx.x; i < OCP * a.Cg * K; i += 256) {
+    const int o = i % OCP, ck = i / OCP;
+    wl[i] = o < a.Og ? a.w[(size_t)(a.o0 + o) * a.Cg * K + ck] : 0.f;
+  }
+  __syncthreads();
+  const long long npix = (long long)a.B * a.Ho * a.Wo;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix) return;
+  const int x = (int)(idx % a.Wo);
+  const int y = (int)((idx / a.Wo) % a.Ho);
+  const int b = (int)(idx / ((long long)a.Wo * a.Ho));
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+  float g[OCP];
+#pragma unroll
+  for (int o = 0; o < OCP; ++o)
+    g[o] = o < a.Og ? a.gout[((size_t)b * a.Co + a.o0 + o) * plane_o + (size_t)y * a.Wo + x] : 0.f;
+  const int cpd = a.C / a.DG;
+  for (int cl = 0; cl < a.Cg; ++cl) {
+    const int c = a.c0 + cl;
+    const int dgi = c / cpd;
+    const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
+    float* gplane = a.gin + ((size_t)b * a.C + c) * a.H * a.W;
+    const size_t obase = ((size_t)b * a.DG + dgi) * 2 * K * plane_o + (size_t)y * a.Wo + x;
+    for (int k = 0; k < K; ++k) {
+      const int i = k / a.kw, j = k % a.kw;
+      const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
+      const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
+      float gc = 0.f;  // d loss / d column(c,k) at this pixel
+      const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OCP);
+#pragma unroll
+      for (int o = 0; o < OCP / 4; ++o) {
+        const float4 w4 = wk[o];
+        gc = fmaf(w4.x, g[4 * o], gc);
+        gc = fmaf(w4.y, g[4 * o + 1], gc);
+        gc = fmaf(w4.z, g[4 * o + 2], gc);
+        gc = fmaf(w4.w, g[4 * o + 3], gc);
+      }
+      float gh = 0.f, gw = 0.f;
+      if (dcn_inside(h, w, a.H, a.W)) {
+        const int hl = (int)floorf(h), wl_ = (int)floorf(w);
+        const int hh_ = hl + 1, wh = wl_ + 1;
+        const float lh = h - hl, lw = w - wl_, hh = 1.f - lh, hw = 1.f - lw;
+        const bool ok1 = hl >= 0 && wl_ >= 0, ok2 = hl >= 0 && wh <= a.W - 1;
+        const bool ok3 = hh_ <= a.H - 1 && wl_ >= 0, ok4 = hh_ <= a.H - 1 && wh <= a.W - 1;
+        const float v1 = ok1 ? plane[hl * a.W + wl_] : 0.f, v2 = ok2 ? plane[hl * a.W + wh] : 0.f;
+        const float v3 = ok3 ? plane[hh_ * a.W + wl_] : 0.f, v4 = ok4 ? plane[hh_ * a.W + wh] : 0.f;
+        // d sample / d h, d w (deform_im2col_cuda.cuh:82-124)
+        gh = gc * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+        gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
+        if (ok1) atomicAdd(gplane + hl * a.W + wl_, gc * hh * hw);
+        if (ok2) atomicAdd(gplane + hl * a.W + wh, gc * hh * lw);
+        if (ok3) atomicAdd(gplane + hh_ * a.W + wl_, gc * lh * hw);
+        if (ok4) atomicAdd(gplane + hh_ * a.W + wh, gc * lh * lw);
+      }
+      // input channels that share a deformable group add up in channel order (the group's first
+      // channel stores; a group that straddles conv groups is finished by the later launch)
+      float* gp = a.goff + obase + (size_t)(2 * k) * plane_o;
+      const bool first = c % cpd == 0;
+      gp[0] = first ? gh : gp[0] + gh;
+      gp[plane_o] = first ? gw : gp[plane_o] + gw;
+    }
+  }
+}
+
+// weight gradient: per block of 256 pixels, per input channel: the K samples and the Og output
+// gradients of every pixel go through LDS; thread t owns the (o,k) pair t and dots 256 pixels.
+__global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.kh * a.kw;
+  constexpr int LD = 257;            // padded row: (row + p) mod 32 banks
+  float* gl = sm;                    // [Og][LD]
+  float* vl = sm + a.Og * LD;        // [K][LD]
+  const long long npix = (long long)a.B * a.Ho * a.Wo;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < npix;
+  const int x = live ? (int)(idx % a.Wo) : 0;
+  const int y = live ? (int)((idx / a.Wo) % a.Ho) : 0;
+  const int b = live ? (int)(idx / ((long long)a.Wo * a.Ho)) : 0;
+  const size_t plane_o = (size_t)a.Ho * a.Wo;
+  for (int o = 0; o < a.Og; ++o)
+    gl[o * LD + threadIdx.x] = live ? a.gout[((size_t)b * a.Co + a.o0 + o) * plane_o + (size_t)y * a.Wo + x] : 0.f;
+  const int cpd = a.C / a.DG;
+  const int npair = a.Og * K;
+  float* part = a.partial + (size_t)blockIdx.x * a.Og * a.Cg * K;
+  for (int cl = 0; cl < a.Cg; ++cl) {
+    const int c = a.c0 + cl;
+    const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
+    const size_t obase = ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + (size_t)y * a.Wo + x;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+      float val = 0.f;
+      if (live) {
+        const int i = k / a.kw, j = k % a.kw;
+        const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
+        const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
+        if (dcn_inside(h, w, a.H, a.W)) val = dcn_sample(plane, a.H, a.W, h, w);
+      }
+      vl[k * LD + threadIdx.x] = val;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < npair; t += 256) {
+      const int o = t / K, k = t % K;
+      const float* gr = gl + o * LD;
+      const float* vr = vl + k * LD;
+      float s0 = 0.f, s1 = 0.f;
+      for (int p = 0; p < 256; p += 2) {
+        s0 = fmaf(gr[p], vr[p], s0);
+        s1 = fmaf(gr[p + 1], vr[p + 1], s1);
+      }
+      part[((size_t)o * a.Cg + cl) * K + k] = s0 + s1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dcn_weight_reduce_kernel(const float* partial, float* gw, int blocks,
+                                                                int n, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * n + e];
+  gw[e] = accumulate ? gw[e] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* gout, float* gb, int B, int Co,
+                                                            long long hw, int accumulate) {
+  __shared__ float red[4];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (long long i = threadIdx.x; i < hw; i += 256) s += gout[((size_t)b * Co + o) * hw + i];
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    gb[o] = accumulate ? gb[o] + t : t;
+  }
+}
+
+int fill_common(DcnArgs& a, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                int dh, int dw, int G, int DG, int* Ho, int* Wo) {
+  HR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && kh > 0 && kw > 0, "deform_conv: empty shape");
+  HR_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "deform_conv: bad stride/pad/dilation");
+  HR_REQUIRE(G >= 1 && C % G == 0 && Co % G == 0, "deform_conv: channels not divisible by groups %d", G);
+  HR_REQUIRE(DG >= 1 && C % DG == 0, "deform_conv: channels not divisible by deformable_groups %d", DG);
+  *Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  *Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+  HR_REQUIRE(*Ho > 0 && *Wo > 0, "deform_conv: empty output");
+  a.B = B; a.C = C; a.H = H; a.W = W; a.Co = Co; a.Ho = *Ho; a.Wo = *Wo; a.kh = kh; a.kw = kw;
+  a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw; a.dh = dh; a.dw = dw; a.DG = DG;
+  return HR_OK;
+}
+
+}  // namespace
+
+extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset, const float* weight,
+                                         const float* bias, float* output, int B, int C, int H, int W, int Co,
+                                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                         int groups, int deformable_groups, hr_stream_t stream) {
+  DcnArgs a = {};
+  int Ho, Wo;
+  if (int e = fill_common(a, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, &Ho, &Wo))
+    return e;
+  HR_REQUIRE(input && offset && weight && output, "deform_conv_forward: null pointer");
+  a.in = input; a.off = offset; a.w = weight; a.bias = bias; a.out = output;
+  const int Cg = C / groups, Og = Co / groups, K = kh * kw;
+  HR_REQUIRE((size_t)OC * Cg * K * 4 <= 96 * 1024, "deform_conv_forward: C/groups * kh * kw = %d too large", Cg * K);
+  const long long npix = (long long)B * Ho * Wo;
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
+  for (int g = 0; g < groups; ++g) {
+    a.c0 = g * Cg; a.Cg = Cg;
+    for (int o = 0; o < Og; o += OC) {
+      const int ocn = Og - o < OC ? Og - o : OC;
+      hipLaunchKernelGGL(dcn_fwd_kernel, dim3(blocks), dim3(256), (size_t)OC * Cg * K * 4, (hipStream_t)stream, a,
+                         g * Og + o, ocn);
+    }
+  }
+  return hr_check_launch("deform_conv_forward");
+}
+
+extern "C" int hrnet_deform_conv_wgrad_blocks(int B, int Ho, int Wo) {
+  return (int)(((long long)B * Ho * Wo + 255) / 256);
+}
+
+extern "C" int hrnet_deform_conv_backward(const float* input, const float* offset, const float* weight,
+                                          const float* grad_output, float* grad_input, float* grad_offset,
+                                          float* grad_weight, float* grad_bias, float* scratch, int B, int C,
+                                          int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                                          int dh, int dw, int groups, int deformable_groups,
+                                          hr_stream_t stream) {
+  DcnArgs a = {};
+  int Ho, Wo;
+  if (int e = fill_common(a, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, &Ho, &Wo))
+    return e;
+  HR_REQUIRE(input && offset && weight && grad_output && grad_input && grad_offset && grad_weight && scratch,
+             "deform_conv_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  a.in = input; a.off = offset; a.w = weight; a.gout = grad_output; a.gin = grad_input; a.goff = grad_offset;
+  a.partial = scratch;
+  const int Cg = C / groups, Og = Co / groups, K = kh * kw;
+  HR_REQUIRE(Og <= 64, "deform_conv_backward: out_channels/groups = %d > 64 not supported", Og);
+  HR_REQUIRE((size_t)(Og <= 32 ? 32 : 64) * Cg * K * 4 <= 96 * 1024,
+             "deform_conv_backward: C/groups * kh * kw = %d too large", Cg * K);
+  HR_REQUIRE((size_t)(Og + K) * 257 * 4 <= 150 * 1024, "deform_conv_backward: Og + kh*kw too large for LDS");
+  const long long npix = (long long)B * Ho * Wo;
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
+  hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
+  for (int g = 0; g < groups; ++g) {
+    a.c0 = g * Cg; a.Cg = Cg; a.o0 = g * Og; a.Og = Og;
+    if (Og <= 32)
+      hipLaunchKernelGGL(dcn_bwd_data_kernel<32>, dim3(blocks), dim3(256), (size_t)32 * Cg * K * 4, s, a);
+    else
+      hipLaunchKernelGGL(dcn_bwd_data_kernel<64>, dim3(blocks), dim3(256), (size_t)64 * Cg * K * 4, s, a);
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(blocks), dim3(256), (size_t)(Og + K) * 257 * 4, s, a);
+    const int n = Og * Cg * K;
+    hipLaunchKernelGGL(dcn_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch,
+                       grad_weight + (size_t)g * n, (int)blocks, n, 0);
+  }
+  if (grad_bias)
+    hipLaunchKernelGGL(dcn_bias_grad_kernel, dim3(Co), dim3(256), 0, s, grad_output, grad_bias, B, Co,
+                       (long long)Ho * Wo, 0);
+  return hr_check_launch("deform_conv_backward");
+}

@@ -74,10 +74,13 @@ _SIGS = {
     'hrnet_joints_loss_fwd': [_c_vp] * 4 + [_c_int] * 2 + [_c_vp],
     'hrnet_joints_loss_bwd': [_c_vp] * 5 + [_c_int] * 2 + [_c_vp],
     'hrnet_adam_step': [_c_vp] * 4 + [_c_i64] + [_c_float] * 5 + [_c_int, _c_float, _c_vp],
+    'hrnet_deform_conv_forward': [_c_vp] * 5 + [_c_int] * 15 + [_c_vp],
+    'hrnet_deform_conv_wgrad_blocks': [_c_int] * 3,
+    'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
-          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name'}
+          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 
 _lib = None

@@ -264,6 +264,31 @@ int hrnet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, hr_stream_t stream);
 
+/*
+ * Deformable convolution v1 (lib/deformable_conv/functions/deform_conv_func.py:18-66, which binds
+ * DCN.deform_conv_forward / deform_conv_backward of src/cuda/deform_conv_cuda.cu:19,139; sampling
+ * rule src/cuda/deform_im2col_cuda.cuh:24-189). All tensors NCHW f32:
+ *   input [B,C,H,W], offset [B, deformable_groups*2*kh*kw, Ho, Wo] (per tap: dy plane, dx plane),
+ *   weight [Co, C/groups, kh, kw], bias [Co] or NULL, output [B,Co,Ho,Wo].
+ * No column buffer is materialised, so the reference's im2col_step has no counterpart here (any
+ * value gives the same result - the reference's own invariant, test.py:218-248).
+ * backward: grad_input is accumulated with float atomics like the reference's col2im (zeroed
+ * inside); grad_bias may be NULL; scratch holds hrnet_deform_conv_wgrad_blocks() *
+ * (Co/groups)*(C/groups)*kh*kw floats. Limits: Co/groups <= 64 for backward, weight slice of one
+ * group <= 96 KB.
+ */
+int hrnet_deform_conv_forward(const float* input, const float* offset, const float* weight,
+                              const float* bias, float* output, int B, int C, int H, int W, int Co,
+                              int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                              int groups, int deformable_groups, hr_stream_t stream);
+int hrnet_deform_conv_wgrad_blocks(int B, int Ho, int Wo);
+int hrnet_deform_conv_backward(const float* input, const float* offset, const float* weight,
+                               const float* grad_output, float* grad_input, float* grad_offset,
+                               float* grad_weight, float* grad_bias, float* scratch, int B, int C,
+                               int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                               int dh, int dw, int groups, int deformable_groups,
+                               hr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

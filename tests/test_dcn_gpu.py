@@ -1,0 +1,148 @@
+"""Deformable convolution on the HIP library vs the CPU oracle and the reference's own invariants
+(lib/deformable_conv/test.py). Tolerances: f32 arithmetic, sums of <= a few hundred products:
+1e-4 absolute on O(1..10) values; grad_input uses float atomics (order-dependent) like the
+reference's col2im."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcn_cpu as D
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _case(seed, B, C, H, W, Co, k, groups, DG, stride, pad, dil, scale=2.0):
+    rng = np.random.default_rng(seed)
+    Ho, Wo = D._out_size(H, W, k, k, (stride, stride), (pad, pad), (dil, dil))
+    return dict(input=rng.standard_normal((B, C, H, W)).astype(np.float32),
+                offset=(rng.standard_normal((B, DG * 2 * k * k, Ho, Wo)) * scale).astype(np.float32),
+                weight=rng.standard_normal((Co, C // groups, k, k)).astype(np.float32),
+                bias=rng.random(Co).astype(np.float32), stride=(stride, stride), padding=(pad, pad),
+                dilation=(dil, dil), groups=groups, DG=DG)
+
+
+def _run(c, with_grad=False, seed=9, im2col_step=64):
+    from deformable_conv import DeformConvFunction
+    t = {k: torch.from_numpy(c[k]).to(DEV).requires_grad_(with_grad) for k in ('input', 'offset', 'weight', 'bias')}
+    out = DeformConvFunction.apply(t['input'], t['offset'], t['weight'], t['bias'], c['stride'], c['padding'],
+                                   c['dilation'], c['groups'], c['DG'], im2col_step)
+    if not with_grad:
+        return out.cpu().numpy()
+    go = np.random.default_rng(seed).standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(DEV))
+    return out.detach().cpu().numpy(), go, {k: v.grad.cpu().numpy() for k, v in t.items()}
+
+
+def test_zero_offset_equals_conv2d_with_groups():
+    """reference test.py:37-69"""
+    from deformable_conv import DeformConv
+    torch.manual_seed(3)
+    dcn = DeformConv(4, 4, (3, 3), stride=1, padding=1, dilation=1, groups=2, deformable_groups=1,
+                     im2col_step=1).to(DEV)
+    x = torch.randn(2, 4, 4, 4, device=DEV)
+    off = torch.zeros(2, 18, 4, 4, device=DEV)
+    out = dcn(x, off)
+    ref = F.conv2d(x.cpu(), dcn.weight.detach().cpu(), dcn.bias.detach().cpu(), 1, 1, 1, 2)
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+
+
+def test_identity_kernel_is_exact():
+    """reference test.py:113-141 (d < 1e-10: the op must be exact here)"""
+    from deformable_conv import DeformConv
+    dcn = DeformConv(4, 4, (3, 3), stride=1, padding=1, dilation=1, groups=2, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        dcn.weight.zero_()
+        dcn.bias.zero_()
+        for q in range(4):
+            dcn.weight[q, q % 2, 1, 1] = 1.0
+    x = torch.randn(2, 4, 4, 4, device=DEV)
+    out = dcn(x, torch.zeros(2, 18, 4, 4, device=DEV))
+    assert float((out - x).abs().max()) == 0.0
+
+
+def test_im2col_step_does_not_change_the_result():
+    """reference test.py:177-248"""
+    c = _case(11, 2, 4, 4, 4, 4, 3, 2, 1, 1, 1, 1)
+    a, _, ga = _run(c, True, im2col_step=1)
+    b, _, gb = _run(c, True, im2col_step=2)
+    assert np.array_equal(a, b)
+    for k in ('offset', 'weight', 'bias'):
+        assert np.array_equal(ga[k], gb[k]), k
+    assert np.abs(ga['input'] - gb['input']).max() < 1e-5          # atomics: order may differ
+    from deformable_conv import DeformConvFunction
+    with pytest.raises(ValueError, match='im2col_step'):
+        z = torch.zeros
+        DeformConvFunction.apply(z(3, 4, 4, 4, device=DEV), z(3, 18, 4, 4, device=DEV), z(4, 4, 3, 3, device=DEV),
+                                 None, 1, 1, 1, 1, 1, 2)
+
+
+CASES = [
+    # B, C, H, W, Co, k, groups, DG, stride, pad, dil
+    (2, 4, 4, 4, 4, 3, 2, 1, 1, 1, 1),          # the reference test's shape
+    (2, 4, 9, 7, 6, 3, 1, 2, 2, 1, 1),          # stride 2, ragged size
+    (1, 6, 11, 13, 4, 3, 2, 3, 1, 2, 2),        # deformable groups straddle conv groups
+    (3, 21, 16, 16, 21, 3, 1, 21, 1, 6, 6),     # PoseAggr geometry (pose_hrnet_PoseAggr.py:500-516)
+    (1, 8, 10, 10, 40, 3, 1, 1, 1, 1, 1),       # > 32 output channels: two forward passes
+    (2, 3, 8, 8, 5, 1, 1, 1, 1, 0, 1),          # 1x1 kernel
+    (1, 2, 6, 20, 2, 5, 1, 2, 1, 2, 1),         # 5x5 kernel
+]
+
+
+@pytest.mark.parametrize('shape', CASES)
+def test_forward_and_backward_match_the_oracle(shape):
+    c = _case(21 + sum(shape), *shape)
+    out, go, g = _run(c, True)
+    c64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    ref = D.deform_conv_forward(**c64)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out - ref).max() < 2e-5 * scale
+    gi, goff, gw, gb = D.deform_conv_backward(c64['input'], c64['offset'], c64['weight'], go.astype(np.float64),
+                                              c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    for name, want in (('input', gi), ('offset', goff), ('weight', gw), ('bias', gb)):
+        s = max(1.0, float(np.abs(want).max()))
+        assert np.abs(g[name] - want).max() < 5e-5 * s, name
+
+
+def test_large_offsets_fall_outside_and_read_zero():
+    c = _case(5, 2, 4, 8, 8, 4, 3, 1, 1, 1, 1, 1, scale=20.0)
+    out = _run(c)
+    c64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    assert np.abs(out - D.deform_conv_forward(**c64)).max() < 1e-4
+    c['offset'][:] = 1e6
+    out = _run(c)
+    assert np.array_equal(out, np.broadcast_to(c['bias'].reshape(1, -1, 1, 1), out.shape))
+
+
+def test_poseaggr_scale_linearity_and_zero_offset():
+    """config 5 size (B=64, 21 ch, 64x64, dilation 6): size-independent properties - zero offsets equal
+    the dilated convolution, and the op is linear in the input for fixed offsets."""
+    rng = np.random.default_rng(0)
+    B = 64
+    x = torch.from_numpy(rng.standard_normal((B, 21, 64, 64)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((21, 21, 3, 3)) * 0.1).astype(np.float32)).to(DEV)
+    from deformable_conv import DeformConvFunction
+    zero = torch.zeros(B, 21 * 18, 64, 64, device=DEV)
+    out = DeformConvFunction.apply(x, zero, w, None, 1, 6, 6, 1, 21, 64)
+    ref = F.conv2d(x, w, None, 1, 6, 6)
+    assert float((out - ref).abs().max()) < 1e-4
+    off = torch.from_numpy((rng.standard_normal((B, 21 * 18, 64, 64)) * 3).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, 21, 64, 64)).astype(np.float32)).to(DEV)
+    f = lambda t: DeformConvFunction.apply(t, off, w, None, 1, 6, 6, 1, 21, 64)
+    lin = f(x + 2 * x2) - (f(x) + 2 * f(x2))
+    assert float(lin.abs().max()) < 1e-4
+
+
+def test_bad_arguments_fail_loudly():
+    from deformable_conv import DeformConvFunction
+    z = torch.zeros
+    with pytest.raises(ValueError, match='offset shape'):
+        DeformConvFunction.apply(z(1, 4, 4, 4, device=DEV), z(1, 18, 5, 4, device=DEV), z(4, 4, 3, 3, device=DEV),
+                                 None, 1, 1, 1, 1, 1, 64)
+    with pytest.raises(TypeError):
+        DeformConvFunction.apply(z(1, 4, 4, 4, device=DEV).half(), z(1, 18, 4, 4, device=DEV),
+                                 z(4, 4, 3, 3, device=DEV), None, 1, 1, 1, 1, 1, 64)
+    with pytest.raises(RuntimeError, match='deformable_groups'):
+        DeformConvFunction.apply(z(1, 4, 4, 4, device=DEV), z(1, 54, 4, 4, device=DEV), z(4, 4, 3, 3, device=DEV),
+                                 None, 1, 1, 1, 1, 3, 64)
