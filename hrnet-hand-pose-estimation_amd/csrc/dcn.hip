@@ -159,63 +159,159 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnArgs a) {
   }
 }
 
-// weight gradient: per block of 256 pixels, per input channel: the K samples and the Og output
-// gradients of every pixel go through LDS; thread t owns the (o,k) pair t and dots 256 pixels.
+// Fast path of the data gradients when the input planes of one deformable group fit LDS: a block
+// owns (image b, deformable group) and accumulates the scattered input gradient of the group's
+// channels in LDS (ds_add_f32) instead of global atomics, reads each offset once for all channels of
+// the group, and writes the finished planes with plain coalesced stores. Requires every deformable
+// group to lie inside one conv group.
+template <int OCP>
+__global__ __launch_bounds__(256) void dcn_bwd_data_lds_kernel(DcnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.kh * a.kw;
+  const int cpd = a.C / a.DG;
+  const int HW = a.H * a.W;
+  float* wl = sm;                       // [cpd*K][OCP], zero beyond Og
+  float* gpl = sm + cpd * K * OCP;      // [cpd][H*W]
+  const int c_first = a.c0 + blockIdx.x * cpd;          // first channel of this deformable group
+  const int dgi = c_first / cpd;
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < OCP * cpd * K; i += 256) {
+    const int o = i % OCP, ck = i / OCP;
+    wl[i] = o < a.Og ? a.w[((size_t)(a.o0 + o) * a.Cg + (c_first - a.c0)) * K + ck] : 0.f;
+  }
+  for (int i = threadIdx.x; i < cpd * HW; i += 256) gpl[i] = 0.f;
+  __syncthreads();
+  const int plane_o = a.Ho * a.Wo;
+  const float* in_b = a.in + ((size_t)b * a.C + c_first) * HW;
+  for (int p0 = 0; p0 < plane_o; p0 += 256) {
+    const int p = p0 + threadIdx.x;
+    if (p >= plane_o) break;
+    const int y = p / a.Wo, x = p % a.Wo;
+    float g[OCP];
+#pragma unroll
+    for (int o = 0; o < OCP; ++o)
+      g[o] = o < a.Og ? a.gout[((size_t)b * a.Co + a.o0 + o) * plane_o + p] : 0.f;
+    const size_t obase = ((size_t)b * a.DG + dgi) * 2 * K * plane_o + p;
+    for (int k = 0; k < K; ++k) {
+      const int i = k / a.kw, j = k % a.kw;
+      const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
+      const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
+      float gh = 0.f, gw = 0.f;
+      if (dcn_inside(h, w, a.H, a.W)) {
+        const int hl = (int)floorf(h), wl_ = (int)floorf(w);
+        const int hh_ = hl + 1, wh = wl_ + 1;
+        const float lh = h - hl, lw = w - wl_, hh = 1.f - lh, hw = 1.f - lw;
+        const bool ok1 = hl >= 0 && wl_ >= 0, ok2 = hl >= 0 && wh <= a.W - 1;
+        const bool ok3 = hh_ <= a.H - 1 && wl_ >= 0, ok4 = hh_ <= a.H - 1 && wh <= a.W - 1;
+        for (int cl = 0; cl < cpd; ++cl) {
+          float gc = 0.f;
+          const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OCP);
+#pragma unroll
+          for (int o = 0; o < OCP / 4; ++o) {
+            const float4 w4 = wk[o];
+            gc = fmaf(w4.x, g[4 * o], gc);
+            gc = fmaf(w4.y, g[4 * o + 1], gc);
+            gc = fmaf(w4.z, g[4 * o + 2], gc);
+            gc = fmaf(w4.w, g[4 * o + 3], gc);
+          }
+          const float* plane = in_b + (size_t)cl * HW;
+          float* gp = gpl + cl * HW;
+          const float v1 = ok1 ? plane[hl * a.W + wl_] : 0.f, v2 = ok2 ? plane[hl * a.W + wh] : 0.f;
+          const float v3 = ok3 ? plane[hh_ * a.W + wl_] : 0.f, v4 = ok4 ? plane[hh_ * a.W + wh] : 0.f;
+          gh = fmaf(gc, -hw * v1 - lw * v2 + hw * v3 + lw * v4, gh);
+          gw = fmaf(gc, -hh * v1 + hh * v2 - lh * v3 + lh * v4, gw);
+          if (ok1) atomicAdd(gp + hl * a.W + wl_, gc * hh * hw);
+          if (ok2) atomicAdd(gp + hl * a.W + wh, gc * hh * lw);
+          if (ok3) atomicAdd(gp + hh_ * a.W + wl_, gc * lh * hw);
+          if (ok4) atomicAdd(gp + hh_ * a.W + wh, gc * lh * lw);
+        }
+      }
+      a.goff[obase + (size_t)(2 * k) * plane_o] = gh;
+      a.goff[obase + (size_t)(2 * k + 1) * plane_o] = gw;
+    }
+  }
+  __syncthreads();
+  float* out = a.gin + ((size_t)b * a.C + c_first) * HW;
+  for (int i = threadIdx.x; i < cpd * HW; i += 256) out[i] = gpl[i];
+}
+
+// weight gradient: a block walks WCH chunks of 256 pixels; per chunk and input channel the K samples
+// and the Og output gradients of every pixel go through LDS, thread t owns the (o,k) pair t, dots the
+// 256 pixels and keeps its running sums in LDS. One partial [Og][Cg][K] per block, summed in fixed
+// order by dcn_weight_reduce_kernel (deterministic).
+constexpr int WCH = 1;  // more chunks per block leave too few blocks in flight at B*Ho*Wo ~ 2.6e5
+
 __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = a.kh * a.kw;
   constexpr int LD = 257;            // padded row: (row + p) mod 32 banks
   float* gl = sm;                    // [Og][LD]
   float* vl = sm + a.Og * LD;        // [K][LD]
+  float* accl = vl + K * LD;         // [Og][Cg][K], element (o,cl,k) owned by thread (o*K+k) % 256
   const long long npix = (long long)a.B * a.Ho * a.Wo;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = idx < npix;
-  const int x = live ? (int)(idx % a.Wo) : 0;
-  const int y = live ? (int)((idx / a.Wo) % a.Ho) : 0;
-  const int b = live ? (int)(idx / ((long long)a.Wo * a.Ho)) : 0;
   const size_t plane_o = (size_t)a.Ho * a.Wo;
-  for (int o = 0; o < a.Og; ++o)
-    gl[o * LD + threadIdx.x] = live ? a.gout[((size_t)b * a.Co + a.o0 + o) * plane_o + (size_t)y * a.Wo + x] : 0.f;
   const int cpd = a.C / a.DG;
   const int npair = a.Og * K;
-  float* part = a.partial + (size_t)blockIdx.x * a.Og * a.Cg * K;
-  for (int cl = 0; cl < a.Cg; ++cl) {
-    const int c = a.c0 + cl;
-    const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
-    const size_t obase = ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + (size_t)y * a.Wo + x;
+  for (int t = threadIdx.x; t < npair; t += 256)
+    for (int cl = 0; cl < a.Cg; ++cl) accl[((t / K) * a.Cg + cl) * K + t % K] = 0.f;
+  for (int ch = 0; ch < WCH; ++ch) {
+    const long long first = ((long long)blockIdx.x * WCH + ch) * 256;
+    if (first >= npix) break;
+    const long long idx = first + threadIdx.x;
+    const bool live = idx < npix;
+    const int x = live ? (int)(idx % a.Wo) : 0;
+    const int y = live ? (int)((idx / a.Wo) % a.Ho) : 0;
+    const int b = live ? (int)(idx / ((long long)a.Wo * a.Ho)) : 0;
     __syncthreads();
-    for (int k = 0; k < K; ++k) {
-      float val = 0.f;
-      if (live) {
-        const int i = k / a.kw, j = k % a.kw;
-        const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
-        const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
-        if (dcn_inside(h, w, a.H, a.W)) val = dcn_sample(plane, a.H, a.W, h, w);
+    for (int o = 0; o < a.Og; ++o)
+      gl[o * LD + threadIdx.x] =
+          live ? a.gout[((size_t)b * a.Co + a.o0 + o) * plane_o + (size_t)y * a.Wo + x] : 0.f;
+    for (int cl = 0; cl < a.Cg; ++cl) {
+      const int c = a.c0 + cl;
+      const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
+      const size_t obase = ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + (size_t)y * a.Wo + x;
+      __syncthreads();
+      for (int k = 0; k < K; ++k) {
+        float val = 0.f;
+        if (live) {
+          const int i = k / a.kw, j = k % a.kw;
+          const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
+          const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
+          if (dcn_inside(h, w, a.H, a.W)) val = dcn_sample(plane, a.H, a.W, h, w);
+        }
+        vl[k * LD + threadIdx.x] = val;
       }
-      vl[k * LD + threadIdx.x] = val;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < npair; t += 256) {
-      const int o = t / K, k = t % K;
-      const float* gr = gl + o * LD;
-      const float* vr = vl + k * LD;
-      float s0 = 0.f, s1 = 0.f;
-      for (int p = 0; p < 256; p += 2) {
-        s0 = fmaf(gr[p], vr[p], s0);
-        s1 = fmaf(gr[p + 1], vr[p + 1], s1);
+      __syncthreads();
+      for (int t = threadIdx.x; t < npair; t += 256) {
+        const int o = t / K, k = t % K;
+        const float* gr = gl + o * LD;
+        const float* vr = vl + k * LD;
+        float s0 = 0.f, s1 = 0.f;
+        for (int p = 0; p < 256; p += 2) {
+          s0 = fmaf(gr[p], vr[p], s0);
+          s1 = fmaf(gr[p + 1], vr[p + 1], s1);
+        }
+        accl[(o * a.Cg + cl) * K + k] += s0 + s1;
       }
-      part[((size_t)o * a.Cg + cl) * K + k] = s0 + s1;
     }
   }
+  float* part = a.partial + (size_t)blockIdx.x * a.Og * a.Cg * K;
+  for (int t = threadIdx.x; t < npair; t += 256)
+    for (int cl = 0; cl < a.Cg; ++cl) {
+      const int e = ((t / K) * a.Cg + cl) * K + t % K;
+      part[e] = accl[e];
+    }
 }
 
+// one wave per weight element: lanes stride over the per-block partials, fixed-shape tree at the end
 __global__ __launch_bounds__(256) void dcn_weight_reduce_kernel(const float* partial, float* gw, int blocks,
                                                                 int n, int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= n) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(size_t)b * n + e];
-  gw[e] = accumulate ? gw[e] + (float)s : (float)s;
+  float s = 0.f;
+  for (int b = threadIdx.x & 63; b < blocks; b += 64) s += partial[(size_t)b * n + e];
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) gw[e] = accumulate ? gw[e] + s : s;
 }
 
 __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* gout, float* gb, int B, int Co,
@@ -232,6 +328,14 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* gout, f
     const float t = (red[0] + red[1]) + (red[2] + red[3]);
     gb[o] = accumulate ? gb[o] + t : t;
   }
+}
+
+// dynamic LDS beyond the default 64 KB window has to be requested per kernel
+template <typename F>
+void want_lds(F kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
 }
 
 int fill_common(DcnArgs& a, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
@@ -264,6 +368,7 @@ extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset
   HR_REQUIRE((size_t)OC * Cg * K * 4 <= 96 * 1024, "deform_conv_forward: C/groups * kh * kw = %d too large", Cg * K);
   const long long npix = (long long)B * Ho * Wo;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
+  want_lds(dcn_fwd_kernel, (size_t)OC * Cg * K * 4);
   for (int g = 0; g < groups; ++g) {
     a.c0 = g * Cg; a.Cg = Cg;
     for (int o = 0; o < Og; o += OC) {
@@ -276,7 +381,7 @@ extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset
 }
 
 extern "C" int hrnet_deform_conv_wgrad_blocks(int B, int Ho, int Wo) {
-  return (int)(((long long)B * Ho * Wo + 255) / 256);
+  return (int)(((long long)B * Ho * Wo + 256 * WCH - 1) / (256 * WCH));
 }
 
 extern "C" int hrnet_deform_conv_backward(const float* input, const float* offset, const float* weight,
@@ -298,20 +403,32 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
   HR_REQUIRE(Og <= 64, "deform_conv_backward: out_channels/groups = %d > 64 not supported", Og);
   HR_REQUIRE((size_t)(Og <= 32 ? 32 : 64) * Cg * K * 4 <= 96 * 1024,
              "deform_conv_backward: C/groups * kh * kw = %d too large", Cg * K);
-  HR_REQUIRE((size_t)(Og + K) * 257 * 4 <= 150 * 1024, "deform_conv_backward: Og + kh*kw too large for LDS");
+  HR_REQUIRE(((size_t)(Og + K) * 257 + (size_t)Og * Cg * K) * 4 <= 160 * 1024,
+             "deform_conv_backward: weight-gradient tile does not fit LDS (Og %d, Cg %d, taps %d)", Og, Cg, K);
+  const unsigned wblocks = (unsigned)hrnet_deform_conv_wgrad_blocks(B, Ho, Wo);
   const long long npix = (long long)B * Ho * Wo;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
-  hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
+  const int cpd = C / deformable_groups;
+  const size_t lds_fast = ((size_t)cpd * K * (Og <= 32 ? 32 : 64) + (size_t)cpd * H * W) * 4;
+  const bool fast = Cg % cpd == 0 && lds_fast <= 64 * 1024;
+  if (!fast) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
+  if (Og <= 32) want_lds(dcn_bwd_data_kernel<32>, (size_t)32 * Cg * K * 4);
+  else want_lds(dcn_bwd_data_kernel<64>, (size_t)64 * Cg * K * 4);
+  want_lds(dcn_bwd_weight_kernel, ((size_t)(Og + K) * 257 + (size_t)Og * Cg * K) * 4);
   for (int g = 0; g < groups; ++g) {
     a.c0 = g * Cg; a.Cg = Cg; a.o0 = g * Og; a.Og = Og;
-    if (Og <= 32)
+    if (fast && Og <= 32)
+      hipLaunchKernelGGL(dcn_bwd_data_lds_kernel<32>, dim3(Cg / cpd, B), dim3(256), lds_fast, s, a);
+    else if (fast)
+      hipLaunchKernelGGL(dcn_bwd_data_lds_kernel<64>, dim3(Cg / cpd, B), dim3(256), lds_fast, s, a);
+    else if (Og <= 32)
       hipLaunchKernelGGL(dcn_bwd_data_kernel<32>, dim3(blocks), dim3(256), (size_t)32 * Cg * K * 4, s, a);
     else
       hipLaunchKernelGGL(dcn_bwd_data_kernel<64>, dim3(blocks), dim3(256), (size_t)64 * Cg * K * 4, s, a);
-    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(blocks), dim3(256), (size_t)(Og + K) * 257 * 4, s, a);
     const int n = Og * Cg * K;
-    hipLaunchKernelGGL(dcn_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)scratch,
-                       grad_weight + (size_t)g * n, (int)blocks, n, 0);
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(wblocks), dim3(256), ((size_t)(Og + K) * 257 + n) * 4, s, a);
+    hipLaunchKernelGGL(dcn_weight_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)scratch,
+                       grad_weight + (size_t)g * n, (int)wblocks, n, 0);
   }
   if (grad_bias)
     hipLaunchKernelGGL(dcn_bias_grad_kernel, dim3(Co), dim3(256), 0, s, grad_output, grad_bias, B, Co,

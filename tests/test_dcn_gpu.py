@@ -87,6 +87,8 @@ CASES = [
     (1, 8, 10, 10, 40, 3, 1, 1, 1, 1, 1),       # > 32 output channels: two forward passes
     (2, 3, 8, 8, 5, 1, 1, 1, 1, 0, 1),          # 1x1 kernel
     (1, 2, 6, 20, 2, 5, 1, 2, 1, 2, 1),         # 5x5 kernel
+    (1, 80, 6, 6, 8, 3, 1, 1, 1, 1, 1),         # 92 KB weight slice in LDS, global-atomics path
+    (2, 6, 12, 12, 6, 3, 1, 2, 1, 1, 1),        # 3 channels per deformable group on the LDS path
 ]
 
 
