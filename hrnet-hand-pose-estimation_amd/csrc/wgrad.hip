@@ -267,12 +267,17 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   const int tiles = N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
   const int gy = (Cout + c.bco - 1) / c.bco;
   const int gz = (Cin + c.kc - 1) / c.kc;
-  // ~1000 workgroups (4 per CU: the kernel has no software pipelining, occupancy hides its latency);
-  // each split costs one f32 slab of Cout*taps*Cin written and re-read by hrnet_wgrad_reduce
-  int ns = 768 / (gy * gz);
+  // measured on MI355X (scratch/wgrad_micro.py): fastest with ~512 workgroups in total for 3x3 and ~1024
+  // for 1x1 tiles, and only when every split walks the same number of tiles (an uneven split costs
+  // 20-30 %). Each split costs one f32 slab of Cout*taps*Cin written and re-read by hrnet_wgrad_reduce.
+  const int target = ks == 1 ? 1024 : 512;
+  int ns = target / (gy * gz);
   if (ns < 1) ns = 1;
-  if (ns > 128) ns = 128;
+  if (ns > 512) ns = 512;
   if (ns > tiles) ns = tiles;
+  int even = ns;
+  while (even > 1 && tiles % even != 0) --even;
+  if (even * 2 > ns) ns = even;
   return ns;
 }
 
