@@ -32,6 +32,13 @@ struct ConvArgs {
   const float* bias;
   char* y;
   float* stats;
+  // backward-statistics mode (dgrad launches): the statistics rows hold (sum dz, sum dz*yraw) of the
+  // BatchNorm that produced this launch's output gradient, dz = v * [mask > 0], with the mask value
+  // bs_mask (or bs_y) optionally mapped through bs_scale/bs_shift. Replaces a bn_bwd_reduce pass.
+  const char* bs_y;
+  const char* bs_mask;
+  const float* bs_scale;
+  const float* bs_shift;
   int N, H, W, Cin;  // stored input
   int Hz, Wz;        // logical input extent (== H, W unless upz)
   int Ho, Wo, Cout;
@@ -76,8 +83,9 @@ struct ConvCfg {
 // one workgroup per CU. With a single K chunk (Cin <= KC) the weight slice is staged once and
 // stays resident for every tile. BatchNorm statistics accumulate in registers across the tiles
 // and are reduced across lanes / waves once per workgroup.
-template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+// BS: backward-statistics epilogue (input-gradient launches that feed a BatchNorm backward)
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM, bool BS>
+__device__ __forceinline__ void conv_body(const ConvArgs& a) {
   using C = ConvCfg<T, KS, STRIDE, TH, TW, BN, WP, WC, KM>;
   constexpr int VEC = C::VEC;
   __shared__ __attribute__((aligned(16))) char lds[C::LDSB];
@@ -100,7 +108,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   const int nstage = ntile * nch;
   const bool wres = nch == 1;  // weights stay resident in LDS
   const int v = tid % C::VPP;  // this thread's 16-byte vector within a pixel / weight tap (fixed)
-  const bool has_affine = a.in_scale != nullptr;
+  // a backward-statistics launch is an input-gradient conv: raw dY in, no bias (checked by the launcher)
+  const bool has_affine = BS ? false : a.in_scale != nullptr;
+  const bool in_relu = BS ? false : a.in_relu != 0;
 
   // per-lane LDS byte offsets of the MFMA operands
   int aoff[C::FC];
@@ -245,9 +255,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
 
   auto store_stage = [&](int s) {
     if (has_affine) {
-      if (a.in_relu) xform(std::true_type{}, std::true_type{});
+      if (in_relu) xform(std::true_type{}, std::true_type{});
       else xform(std::true_type{}, std::false_type{});
-    } else if (a.in_relu) {
+    } else if (in_relu) {
       xform(std::false_type{}, std::true_type{});
     }
 #pragma unroll
@@ -270,10 +280,55 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
   const bool cok = cbase < a.Cout;
   float bias[C::LANE_C];
 #pragma unroll
-  for (int k = 0; k < C::LANE_C; ++k) bias[k] = (a.bias && cok) ? a.bias[cbase + k] : 0.f;
+  for (int k = 0; k < C::LANE_C; ++k) bias[k] = (!BS && a.bias && cok) ? a.bias[cbase + k] : 0.f;
   float s1[C::LANE_C], s2[C::LANE_C];
 #pragma unroll
   for (int k = 0; k < C::LANE_C; ++k) s1[k] = s2[k] = 0.f;
+  // backward-statistics operands: one lane's LANE_C contiguous channels per pixel of tensors laid out
+  // like the output, fetched before the tile's last K chunk so the epilogue does not wait for them
+  constexpr int LB = C::LANE_C * (int)sizeof(T);        // bytes per lane per pixel: 8 .. 64
+  constexpr int LV = LB >= 16 ? LB / 16 : 1;
+  V16 pre_y[C::FP][LV], pre_m[C::FP][LV];
+  auto lane_load = [&](const char* src, V16* out) {
+    if constexpr (LB >= 16) {
+#pragma unroll
+      for (int q = 0; q < LV; ++q) out[q] = *(const V16*)(src + q * 16);
+    } else {
+      const uint2 q = *(const uint2*)src;
+      out[0] = V16{q.x, q.y, 0u, 0u};
+    }
+  };
+  auto lane_unpack = [&](const V16* in, float* out) {
+    if constexpr (LB >= 16) {
+#pragma unroll
+      for (int q = 0; q < LV; ++q) v16_unpack<T>(in[q], out + q * VEC);
+    } else {
+      float f[VEC];
+      v16_unpack<T>(in[0], f);
+#pragma unroll
+      for (int k = 0; k < C::LANE_C; ++k) out[k] = f[k];
+    }
+  };
+  auto bs_prefetch = [&]() {
+    const int n = __builtin_amdgcn_readfirstlane(ep_n), ty = __builtin_amdgcn_readfirstlane(ep_ty),
+              tx = __builtin_amdgcn_readfirstlane(ep_tx);
+#pragma unroll
+    for (int fp = 0; fp < C::FP; ++fp) {
+      const int p = wp * C::PM + fp * 16 + li;
+      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      if (cok && oy < a.Ho && ox < a.Wo) {
+        const size_t off = ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
+        lane_load(a.bs_y + off, pre_y[fp]);
+        if (a.bs_mask) lane_load(a.bs_mask + off, pre_m[fp]);
+      }
+    }
+  };
+  float bsc[C::LANE_C], bsh[C::LANE_C];
+#pragma unroll
+  for (int k = 0; k < C::LANE_C; ++k) {
+    bsc[k] = (a.bs_scale && cok) ? a.bs_scale[cbase + k] : 1.f;
+    bsh[k] = (a.bs_scale && cok) ? a.bs_shift[cbase + k] : 0.f;
+  }
 
 #ifdef HR_STAMP
   unsigned long long* stamp_buf = (unsigned long long*)a.stats + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32;
@@ -301,6 +356,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       __syncthreads();
       STAMP();
       if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
+#ifndef HR_BS_LATE
+      if constexpr (BS) { if (ch + 1 == nch) bs_prefetch(); }
+#endif
 #pragma unroll
       for (int tp = 0; tp < C::TAPS; ++tp) {
         const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
@@ -345,10 +403,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
       }
       if (pok) {
         char* dst = a.y + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
+        if constexpr (!BS) {
 #pragma unroll
-        for (int k = 0; k < C::LANE_C; ++k) {
-          s1[k] += vals[k];
-          s2[k] += vals[k] * vals[k];
+          for (int k = 0; k < C::LANE_C; ++k) {
+            s1[k] += vals[k];
+            s2[k] += vals[k] * vals[k];
+          }
         }
 #pragma unroll
         for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
@@ -368,6 +428,29 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
             }
             const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
             *(bf16x4*)dst = o;
+          }
+        }
+        if constexpr (BS) {
+#ifdef HR_BS_LATE
+          if (fp == 0) bs_prefetch();
+#endif
+          // vals now hold the finished gradient of this output element
+          float yv[C::LANE_C], mv[C::LANE_C];
+          lane_unpack(pre_y[fp], yv);
+          if (a.bs_mask) {
+            lane_unpack(pre_m[fp], mv);
+#pragma unroll
+            for (int k = 0; k < C::LANE_C; ++k) mv[k] = fmaf(mv[k], bsc[k], bsh[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < C::LANE_C; ++k) mv[k] = fmaf(yv[k], bsc[k], bsh[k]);
+          }
+          const bool masked = a.bs_mask || a.bs_scale;
+#pragma unroll
+          for (int k = 0; k < C::LANE_C; ++k) {
+            const float dz = (!masked || mv[k] > 0.f) ? vals[k] : 0.f;
+            s1[k] += dz;
+            s2[k] = fmaf(dz, yv[k], s2[k]);
           }
         }
       }
@@ -407,6 +490,18 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         a.stats[((size_t)blockIdx.x * 2 + which) * a.Cout + n0 + cl] = s;
     }
   }
+}
+
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+  conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, false>(a);
+}
+
+// the backward-statistics variant keeps two workgroups per CU (the extra operands would otherwise push
+// the register count past 256 / 2)
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
+__global__ __launch_bounds__(256, 2) void conv_bs_kernel(ConvArgs a) {
+  conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, true>(a);
 }
 
 // ---- tile configuration choice (host) --------------------------------------------------
@@ -451,27 +546,33 @@ inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
   return tile_id == 3 ? 2 : 1;
 }
 
+#define LAUNCH_CONV(...)                                                                        \
+  do {                                                                                          \
+    if (a.bs_y) hipLaunchKernelGGL((conv_bs_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);     \
+    else hipLaunchKernelGGL((conv_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);               \
+  } while (0)
+
 template <typename T, int KS, int STRIDE, int KM>
 int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
   dim3 grid((unsigned)tc.gx, (unsigned)((a.Cout + tc.bn - 1) / tc.bn));
   switch (tc.id) {
     case 0:   // (stride-2 convs only use the 8x8 tiles: their halo is (2*T+1)^2)
       if constexpr (STRIDE == 1)
-        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 16, 16, 32, 4, 1, KM>), grid, dim3(256), 0, s, a);
+        LAUNCH_CONV(T, KS, STRIDE, 16, 16, 32, 4, 1, KM);
       break;
     case 1:
       if constexpr (STRIDE == 1)
-        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 16, 64, 2, 2, KM>), grid, dim3(256), 0, s, a);
+        LAUNCH_CONV(T, KS, STRIDE, 8, 16, 64, 2, 2, KM);
       break;
     case 2:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 64, 2, 2, KM>), grid, dim3(256), 0, s, a);
+      LAUNCH_CONV(T, KS, STRIDE, 8, 8, 64, 2, 2, KM);
       break;
     case 4:
       if constexpr (KS == 1)
-        hipLaunchKernelGGL((conv_kernel<T, 1, 1, 8, 16, 128, 2, 2, KM>), grid, dim3(256), 0, s, a);
+        LAUNCH_CONV(T, 1, 1, 8, 16, 128, 2, 2, KM);
       break;
     default:
-      hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, 8, 8, 32, 2, 2, KM>), grid, dim3(256), 0, s, a);
+      LAUNCH_CONV(T, KS, STRIDE, 8, 8, 32, 2, 2, KM);
       break;
   }
   return hr_check_launch("conv2d");
@@ -521,6 +622,14 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.bias = (const float*)op.p[4];
   a.y = (char*)op.p[5];
   a.stats = (float*)op.p[6];
+  a.bs_y = (const char*)op.p[7];
+  a.bs_mask = (const char*)op.p[8];
+  a.bs_scale = (const float*)op.p[9];
+  a.bs_shift = (const float*)op.p[10];
+  HR_REQUIRE(!a.bs_y || a.stats, "conv2d: backward statistics need a rows buffer");
+  HR_REQUIRE(!a.bs_y || (!a.in_scale && !a.bias && !op.i[11]),
+             "conv2d: backward statistics are for input-gradient launches (no input affine / ReLU / bias)");
+  HR_REQUIRE((a.bs_scale == nullptr) == (a.bs_shift == nullptr), "conv2d: mask scale/shift must come together");
   a.N = N; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.in_relu = op.i[11]; a.upz = upz; a.accumulate = op.i[12];
@@ -559,14 +668,28 @@ extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float
   return hr_launch_conv(op, (hipStream_t)stream);
 }
 
+extern "C" int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, float* stats,
+                                     const void* bs_y, const void* bs_mask, const float* bs_scale,
+                                     const float* bs_shift, int N, int H, int W, int Cin, int Ho, int Wo,
+                                     int Cout, int ks, int stride, int upz, int accumulate, hr_stream_t stream) {
+  HrOp op = {};
+  op.kind = HR_OP_CONV;
+  const int iv[13] = {dtype, N, H, W, Cin, Ho, Wo, Cout, ks, stride, upz, 0, accumulate};
+  for (int k = 0; k < 13; ++k) op.i[k] = iv[k];
+  op.p[0] = (void*)x; op.p[1] = (void*)w; op.p[5] = y; op.p[6] = stats;
+  op.p[7] = (void*)bs_y; op.p[8] = (void*)bs_mask; op.p[9] = (void*)bs_scale; op.p[10] = (void*)bs_shift;
+  HR_REQUIRE(bs_y, "conv2d_bwdstats: null bs_y");
+  return hr_launch_conv(op, (hipStream_t)stream);
+}
+
 // Demangled-style name of the kernel instantiation hrnet_conv2d launches for this shape (so that
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
 extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride,
-                                      int upz, char* buf, int buflen) {
+                                      int upz, int bwdstats, char* buf, int buflen) {
   const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride);
   static const int wp[5] = {4, 2, 2, 2, 2}, wc[5] = {1, 2, 2, 2, 2};
   const int kstride = (ks == 1 || upz) ? 1 : stride;
   const int km = conv_km(dtype, ks, Cin, tc.id);
-  return snprintf(buf, buflen, "conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",
-                  ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
+  return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", bwdstats ? "conv_bs_kernel" : "conv_kernel",
+                  dtype == HR_F32 ? "float" : "__bf16", ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
 }

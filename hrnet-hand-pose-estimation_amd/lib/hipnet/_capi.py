@@ -43,8 +43,9 @@ _SIGS = {
     'hrnet_program_run_streams': [ctypes.POINTER(HrOp), _c_int, _pp, _c_int],
     'hrnet_event_destroy': [_c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
+    'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
     'hrnet_conv_tiles': [_c_int] * 6,
-    'hrnet_conv_kernel_name': [_c_int] * 9 + [ctypes.c_char_p, _c_int],
+    'hrnet_conv_kernel_name': [_c_int] * 10 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
     'hrnet_wgrad_splits': [_c_int] * 8,

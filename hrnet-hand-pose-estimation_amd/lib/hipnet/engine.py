@@ -28,7 +28,7 @@ def _round_up(x, m):
 
 
 class Act(object):
-    __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse')
+    __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse', 'bwd_rows')
 
     def __init__(self, name, N, H, W, Cc):
         self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cc
@@ -38,6 +38,7 @@ class Act(object):
         self.bn = None      # BNRec if this is a raw conv output followed by BatchNorm
         self.bn_done = False
         self.nuse = 0       # number of consumers of the logical value
+        self.bwd_rows = None  # (rows tensor, nrows): BN-backward sums gathered by a dgrad epilogue
 
     @property
     def pixels(self):
@@ -396,13 +397,21 @@ class Plan(object):
         blocks = C.call('hrnet_reduce_blocks', y.N, y.H, y.W, y.C)
         self.max_bwd_part = max(self.max_bwd_part, blocks * 2 * y.C)
         m = b.mod
-        i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
-                         ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
-        self._scratch(self.bwd, i, 0, 'bwdpart')
-        j = self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
-                         ptrs=(None, C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+        if y.bwd_rows is not None:
+            # the dgrad conv that finished g_src already gathered (sum dz, sum dz*y) in its epilogue
+            rows, blocks = y.bwd_rows
+            assert sh == 0
+            self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
+                         ptrs=(C.ptr(rows), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
                                C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
-        self._scratch(self.bwd, j, 0, 'bwdpart')
+        else:
+            i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
+                             ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
+            self._scratch(self.bwd, i, 0, 'bwdpart')
+            j = self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
+                             ptrs=(None, C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                                   C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
+            self._scratch(self.bwd, j, 0, 'bwdpart')
         ints = [self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0, 0, 0]
         ptrs = [C.ptr(y.g), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.coef), None]
         if extra is not None:
@@ -428,9 +437,27 @@ class Plan(object):
             elif e[0] == 'sum':
                 for t in e[1]:
                     relu_of[id(t.act)] = t.relu
+        # dgrad epilogue fusion of the BN-backward reduction: the dgrad conv that writes the LAST
+        # contribution to an activation gradient gathers (sum dz, sum dz*y) of the BatchNorm behind it.
+        first_use, producer_sum, use_lanes = {}, {}, {}
+        for ti, (e, ln) in enumerate(zip(self.tape, self.tape_lanes)):
+            if e[0] == 'conv':
+                ins = [e[1].act]
+            elif e[0] == 'sum':
+                ins = [t.act for t in e[1]]
+                producer_sum[id(e[4])] = e
+            elif e[0] == 'cat':
+                ins = [v.act for v in e[1]]
+            else:
+                continue
+            for a in ins:
+                first_use.setdefault(id(a), ti)
+                use_lanes.setdefault(id(a), set()).add(ln)
+        fuse_stats = self.training and os.environ.get('HRNET_FUSE_BWDSTATS', '1') != '0'
+        self.n_fused_bwdstats = 0
         self.inter_gop = None
         in_region = False
-        for e, lane in reversed(list(zip(self.tape, self.tape_lanes))):
+        for ti, (e, lane) in reversed(list(enumerate(zip(self.tape, self.tape_lanes)))):
             self.bwd.lane = lane
             if e[0] in ('fork', 'join'):
                 # a forward join is the backward fork of the same lanes, and vice versa
@@ -518,10 +545,35 @@ class Plan(object):
                 self.bwd.lane = lane
                 if x.g is not None:
                     # input gradient = conv of dY with the transposed kernel (zero-stuffed for stride 2)
+                    ptrs = [C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None, None, None, None, None]
+                    last = (first_use.get(id(x)) == ti and use_lanes.get(id(x)) == {lane}
+                            and x is not self.inter_act)
+                    target = None
+                    if fuse_stats and last and xin.bn is not None and x.nuse == 1:
+                        # x is a raw conv output read through its BatchNorm (+ReLU) by this conv alone
+                        target = x
+                        ptrs[7] = C.ptr(x.t)
+                        if xin.relu:
+                            ptrs[9], ptrs[10] = C.ptr(xin.bn.scale), C.ptr(xin.bn.shift)
+                    elif fuse_stats and last and xin.bn is None and id(x) in producer_sum:
+                        # x is the output of a sum: gather for its first plain BatchNorm term
+                        _, terms, shifts, relu_out, _o = producer_sum[id(x)]
+                        cand = [t for t, sh in zip(terms, shifts)
+                                if t.act.bn is not None and t.act.nuse == 1 and sh == 0 and not t.relu]
+                        if cand:
+                            target = cand[0].act
+                            ptrs[7] = C.ptr(target.t)
+                            ptrs[8] = C.ptr(x.t) if relu_out else None
+                    if target is not None:
+                        nrows = C.call('hrnet_conv_tiles', x.N, x.H, x.W, x.C, ks, stride)
+                        rows = self._f32(nrows * 2 * x.C)
+                        ptrs[6] = C.ptr(rows)
+                        target.bwd_rows = (rows, nrows)
+                        self.n_fused_bwdstats += 1
                     self.bwd.add(C.OP_CONV,
                                  ints=(self.dtid, y.N, y.H, y.W, y.C, x.H, x.W, x.C, ks, stride,
                                        1 if stride == 2 else 0, 0, 1 if x.ginit else 0),
-                                 ptrs=(C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None))
+                                 ptrs=ptrs)
                     x.ginit = True
                 if lane == 0 and not in_region:
                     if self.wlane:

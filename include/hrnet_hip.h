@@ -105,9 +105,23 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                  const float* in_shift, const float* bias, void* y, float* stats, int N, int H,
                  int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int upz,
                  int in_relu, int accumulate, hr_stream_t stream);
+
+/*
+ * Input-gradient convolution that also gathers the statistics of the BatchNorm backward pass of
+ * its output (autograd of pose_hrnet.py:43-57 - the reduction half of native_batch_norm_backward):
+ * y (overwritten or accumulated) is the gradient v of an activation; stats rows receive
+ * (sum dz, sum dz*yraw) per channel with dz = v * [m > 0], m = bs_mask (or bs_y when bs_mask is
+ * NULL) optionally mapped through bs_scale/bs_shift; no mask at all when bs_mask and bs_scale are
+ * both NULL. bs_y / bs_mask are laid out like y. Rows are finished by hrnet_bn_bwd_finalize with
+ * blocks = hrnet_conv_tiles(N,Ho,Wo,Cout,ks,stride).
+ */
+int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, float* stats,
+                          const void* bs_y, const void* bs_mask, const float* bs_scale,
+                          const float* bs_shift, int N, int H, int W, int Cin, int Ho, int Wo,
+                          int Cout, int ks, int stride, int upz, int accumulate, hr_stream_t stream);
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,
-                           char* buf, int buflen);
+                           int bwdstats, char* buf, int buflen);
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);

@@ -279,6 +279,55 @@ def test_batchnorm_backward_through_upsampled_sum(dtype, sh):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('mode', ['bn_relu', 'bn_plain', 'sum_mask'])
+@pytest.mark.parametrize('case', [(2, 16, 16, 32, 32, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 8, 8, 256, 64, 1, 1)])
+def test_dgrad_epilogue_gathers_batchnorm_backward_sums(dtype, mode, case):
+    """hrnet_conv2d_bwdstats: the input-gradient conv also leaves (sum dz, sum dz*y) rows of the
+    BatchNorm behind its output; checked against the same sums taken from the stored gradient."""
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cin, Cout, ks, stride = case
+    g = torch.Generator().manual_seed(31)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks), dtype)
+    Ho = (H + 2 * (ks // 2) - ks) // stride + 1
+    Wo = (W + 2 * (ks // 2) - ks) // stride + 1
+    dy = _q(torch.randn(N, Cout, Ho, Wo, generator=g), dtype)
+    yraw = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    outv = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    prev = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    sc, sf = torch.rand(Cin, generator=g) + 0.5, torch.rand(Cin, generator=g) - 0.5
+    d = hh.DEV
+    wd, _, _ = hh.pack_weights(w, dtype, mode=1)
+    dyd, yd, od = hh.nhwc(dy, dtype), hh.nhwc(yraw, dtype), hh.nhwc(outv, dtype)
+    gx = hh.nhwc(prev, dtype)
+    scd, sfd = sc.to(d), sf.to(d)
+    rows_n = C.call('hrnet_conv_tiles', N, H, W, Cin, ks, stride)
+    rows = torch.full((rows_n, 2, Cin), float('nan'), device=d)
+    C.call('hrnet_conv2d_bwdstats', hh.dt_id(dtype), dyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), rows.data_ptr(),
+           yd.data_ptr(), od.data_ptr() if mode == 'sum_mask' else None,
+           scd.data_ptr() if mode == 'bn_relu' else None, sfd.data_ptr() if mode == 'bn_relu' else None,
+           N, Ho, Wo, Cout, H, W, Cin, ks, stride, 1 if stride == 2 else 0, 1, C.stream_ptr())
+    v = hh.from_nhwc(gx).double()                      # finished gradient as stored
+    # the plain input gradient is still right
+    x = torch.zeros(N, Cin, H, W, requires_grad=True)
+    F.conv2d(x, w, None, stride=stride, padding=ks // 2).backward(dy)
+    assert hh.rel_err(v - prev.double(), x.grad) <= 2 * TOL[dtype]
+    if mode == 'bn_relu':
+        m = (yraw * sc.view(1, -1, 1, 1) + sf.view(1, -1, 1, 1)) > 0
+    elif mode == 'sum_mask':
+        m = outv > 0
+    else:
+        m = torch.ones_like(yraw, dtype=torch.bool)
+    dz = v * m
+    want = torch.stack([dz.sum((0, 2, 3)), (dz * yraw.double()).sum((0, 2, 3))])
+    got = rows.double().sum(0).cpu()
+    assert not torch.isnan(got).any()
+    # the epilogue sums the f32 value before it is rounded for storage; `want` uses the stored one
+    scale = dz.abs().sum((0, 2, 3)).max().item()
+    assert float((got - want).abs().max()) <= 3 * TOL[dtype] * scale
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_bilinear_concat_forward_backward(dtype):
     hh = _h()
     from hipnet import _capi as C
