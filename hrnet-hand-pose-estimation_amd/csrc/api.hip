@@ -49,6 +49,7 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_BIAS_GRAD: e = hr_launch_bias_grad(op, s); break;
     case HR_OP_FILL: e = hr_launch_fill(op, s); break;
     case HR_OP_PACK_TABLE: e = hr_launch_pack_table(op, s); break;
+    case HR_OP_WGRAD_REDUCE_TABLE: e = hr_launch_wgrad_reduce_table(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");
@@ -134,6 +135,13 @@ extern "C" int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n
   op.i[0] = dtype; op.i[1] = n; op.i[2] = total_blocks;
   op.p[0] = (void*)table;
   return hr_launch_pack_table(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_wgrad_reduce_table(const HrWredEnt* table, int n, int total_blocks, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_WGRAD_REDUCE_TABLE);
+  op.i[0] = n; op.i[1] = total_blocks;
+  op.p[0] = (void*)table;
+  return hr_launch_wgrad_reduce_table(op, (hipStream_t)stream);
 }
 
 extern "C" int hrnet_bn_finalize(const float* stats, int tiles, int C, float count, const float* gamma,

@@ -190,3 +190,4 @@ int hr_launch_pack_weights(const HrOp& op, hipStream_t s);
 int hr_launch_bias_grad(const HrOp& op, hipStream_t s);
 int hr_launch_fill(const HrOp& op, hipStream_t s);
 int hr_launch_pack_table(const HrOp& op, hipStream_t s);
+int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s);

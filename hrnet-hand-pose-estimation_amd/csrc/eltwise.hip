@@ -626,44 +626,61 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* parti
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
-                                                           int Cout, int Cin, int ks, int Cout_real,
-                                                           int Cin_real, int kflat, int accumulate) {
-  // block = 64 elements x 4 slab lanes; each lane sums its slabs with 4 loads in flight, LDS adds the
-  // lanes in a fixed order (deterministic)
-  __shared__ float red[4][64];
+// one 64-element chunk x 4 slab lanes: each lane sums its slabs with 4 loads in flight, LDS adds the
+// lanes in a fixed order (deterministic). idx enumerates the slab order (co, tap, ci): coalesced reads.
+__device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* grad, int nsplit, int Cout, int Cin,
+                                                   int ks, int Cout_real, int Cin_real, int kflat, int accumulate,
+                                                   long long base, float (*red)[64]) {
   const int taps = ks * ks;
   const long long total = (long long)Cout_real * Cin_real * taps;
   const size_t slab_sz = (size_t)Cout * (kflat ? 1 : taps) * Cin;
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
-    // idx enumerates the slab order (co, tap, ci) so reads stay coalesced
-    const long long idx = base + el;
-    const bool ok = idx < total;
-    const int ci = (int)(idx % Cin_real);
-    const int t = (int)((idx / Cin_real) % taps);
-    const int co = (int)(idx / ((long long)Cin_real * taps));
-    const size_t soff = kflat ? ((size_t)co * Cin + (size_t)t * Cin_real + ci)
-                              : (((size_t)co * taps + t) * Cin + ci);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (ok) {
-      int k = sl;
-      for (; k + 12 < nsplit; k += 16) {
-        const float v0 = slabs[(size_t)k * slab_sz + soff], v1 = slabs[(size_t)(k + 4) * slab_sz + soff];
-        const float v2 = slabs[(size_t)(k + 8) * slab_sz + soff], v3 = slabs[(size_t)(k + 12) * slab_sz + soff];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-      }
-      for (; k < nsplit; k += 4) s0 += slabs[(size_t)k * slab_sz + soff];
+  const long long idx = base + el;
+  const bool ok = idx < total;
+  const int ci = (int)(idx % Cin_real);
+  const int t = (int)((idx / Cin_real) % taps);
+  const int co = (int)(idx / ((long long)Cin_real * taps));
+  const size_t soff = kflat ? ((size_t)co * Cin + (size_t)t * Cin_real + ci) : (((size_t)co * taps + t) * Cin + ci);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ok) {
+    int k = sl;
+    for (; k + 12 < nsplit; k += 16) {
+      const float v0 = slabs[(size_t)k * slab_sz + soff], v1 = slabs[(size_t)(k + 4) * slab_sz + soff];
+      const float v2 = slabs[(size_t)(k + 8) * slab_sz + soff], v3 = slabs[(size_t)(k + 12) * slab_sz + soff];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    red[sl][el] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (sl == 0 && ok) {
-      const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-      float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
-      *g = accumulate ? *g + s : s;
-    }
-    __syncthreads();
+    for (; k < nsplit; k += 4) s0 += slabs[(size_t)k * slab_sz + soff];
   }
+  red[sl][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && ok) {
+    const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
+    *g = accumulate ? *g + s : s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
+                                                           int Cout, int Cin, int ks, int Cout_real,
+                                                           int Cin_real, int kflat, int accumulate) {
+  __shared__ float red[4][64];
+  const long long total = (long long)Cout_real * Cin_real * ks * ks;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64)
+    wgrad_reduce_chunk(slabs, grad, nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, accumulate, base, red);
+}
+
+// every weight gradient of a backward segment in ONE launch: block b finds its layer by binary search
+__global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const HrWredEnt* tab, int n) {
+  __shared__ float red[4][64];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const HrWredEnt e = tab[lo];
+  wgrad_reduce_chunk(e.slabs, e.grad, e.nsplit, e.Cout_pad, e.Cin_pad, e.ks, e.Cout, e.Cin, e.kflat, e.accumulate,
+                     (long long)((int)blockIdx.x - e.block0) * 64, red);
 }
 
 __global__ __launch_bounds__(256) void fill_zero_kernel(V16* p, long long n16, char* tail, int ntail) {
@@ -919,6 +936,13 @@ int hr_launch_wgrad_reduce(const HrOp& op, hipStream_t s) {
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)op.p[0],
                      (float*)op.p[1], nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, op.i[7]);
   return hr_check_launch("wgrad_reduce");
+}
+
+int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s) {
+  const int n = op.i[0], blocks = op.i[1];
+  HR_REQUIRE(op.p[0] && n >= 1 && blocks >= 1, "wgrad_reduce_table: args");
+  hipLaunchKernelGGL(wgrad_reduce_table_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const HrWredEnt*)op.p[0], n);
+  return hr_check_launch("wgrad_reduce_table");
 }
 
 int hr_launch_fill(const HrOp& op, hipStream_t s) {

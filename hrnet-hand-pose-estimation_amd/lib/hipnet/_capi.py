@@ -22,7 +22,7 @@ class HrOp(ctypes.Structure):
                 ('p', ctypes.c_void_p * 14)]
 
 
-OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT = 17, 18, 19
+OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE = 17, 18, 19, 20
 LANE_SLOT = 18
 
 
@@ -30,6 +30,13 @@ class HrPackEnt(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p), ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32),
                 ('ks', ctypes.c_int32), ('Cout_pad', ctypes.c_int32), ('Cin_pad', ctypes.c_int32),
                 ('mode', ctypes.c_int32), ('block0', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class HrWredEnt(ctypes.Structure):
+    _fields_ = [('slabs', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('nsplit', ctypes.c_int32),
+                ('Cout_pad', ctypes.c_int32), ('Cin_pad', ctypes.c_int32), ('ks', ctypes.c_int32),
+                ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32), ('kflat', ctypes.c_int32),
+                ('accumulate', ctypes.c_int32), ('block0', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 _c_int, _c_float, _c_vp, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
@@ -52,6 +59,7 @@ _SIGS = {
     'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],
     'hrnet_pack_weights': [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
     'hrnet_pack_weights_table': [_c_int, _c_vp, _c_int, _c_int, _c_vp],
+    'hrnet_wgrad_reduce_table': [_c_vp, _c_int, _c_int, _c_vp],
     'hrnet_bn_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 5 + [_c_float, _c_float, _c_int]
                          + [_c_vp] * 4 + [_c_vp],
     'hrnet_sum_terms': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_vp],

@@ -453,6 +453,13 @@ class Plan(object):
             for a in ins:
                 first_use.setdefault(id(a), ti)
                 use_lanes.setdefault(id(a), set()).add(ln)
+        # weight-gradient slab sums are batched: every layer keeps its own slab region and ONE table-driven
+        # launch per lane segment (or per ~16 MB of gradient on lane 0) sums them
+        self.batch_wred = os.environ.get('HRNET_BATCH_WRED', '1') != '0'
+        self._wred = {}            # lane -> pending (slabs tensor, HrWredEnt fields)
+        self._wred_tables = []     # (op index, [entries]) patched with the device table at the end
+        self._wred_bytes = 0
+        self.slab_bytes = 0
         fuse_stats = self.training and os.environ.get('HRNET_FUSE_BWDSTATS', '1') != '0'
         self.n_fused_bwdstats = 0
         self.inter_gop = None
@@ -461,6 +468,8 @@ class Plan(object):
             self.bwd.lane = lane
             if e[0] in ('fork', 'join'):
                 # a forward join is the backward fork of the same lanes, and vice versa
+                for l in sorted(self._wred):
+                    self._flush_wred(l)
                 self.bwd.lane = 0
                 if e[0] == 'join':
                     self.bwd.fork(e[1])
@@ -529,19 +538,30 @@ class Plan(object):
                     self.bwd.sync(lane, self.wlane)
                     self.bwd.lane = self.wlane
                 nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
-                self.max_slab = max(self.max_slab, nsplit * y.C * ks * ks * x.C)
-                i = self.bwd.add(C.OP_WGRAD,
-                                 ints=(self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride,
-                                       1 if xin.relu else 0, nsplit),
-                                 ptrs=(C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
-                                       C.ptr(xin.bn.shift) if xin.bn else None, None))
-                self._scratch(self.bwd, i, 4, 'slab')
-                i = self.bwd.add(C.OP_WGRAD_REDUCE,
-                                 ints=(nsplit, y.C, x.C, ks, crec.Cout, crec.Cin, 1 if crec.stem else 0, 1),
-                                 ptrs=(None, C.ptr(net.grad_of(w))))
-                self._scratch(self.bwd, i, 0, 'slab')
-                if crec.stem:
-                    self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
+                wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit)
+                wptrs = [C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
+                         C.ptr(xin.bn.shift) if xin.bn else None, None]
+                if self.batch_wred:
+                    slabs = self._f32(nsplit * y.C * ks * ks * x.C)
+                    self.slab_bytes += slabs.numel() * 4
+                    wptrs[4] = C.ptr(slabs)
+                    self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
+                    self._wred.setdefault(self.bwd.lane, []).append(dict(
+                        slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
+                        ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
+                        accumulate=1))
+                    if self.bwd.lane == 0:
+                        self._wred_bytes += crec.Cout * crec.Cin * crec.ks * crec.ks * 4
+                else:
+                    self.max_slab = max(self.max_slab, nsplit * y.C * ks * ks * x.C)
+                    i = self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
+                    self._scratch(self.bwd, i, 4, 'slab')
+                    i = self.bwd.add(C.OP_WGRAD_REDUCE,
+                                     ints=(nsplit, y.C, x.C, ks, crec.Cout, crec.Cin, 1 if crec.stem else 0, 1),
+                                     ptrs=(None, C.ptr(net.grad_of(w))))
+                    self._scratch(self.bwd, i, 0, 'slab')
+                    if crec.stem:
+                        self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
                 self.bwd.lane = lane
                 if x.g is not None:
                     # input gradient = conv of dY with the transposed kernel (zero-stuffed for stride 2)
@@ -576,9 +596,57 @@ class Plan(object):
                                  ptrs=ptrs)
                     x.ginit = True
                 if lane == 0 and not in_region:
-                    if self.wlane:
-                        self.bwd.sync(self.wlane, 0)    # this bucket's weight gradients are complete
-                    self.bucket_marks.append((len(self.bwd), crec.prefix))
+                    if self.batch_wred:
+                        if self._wred_bytes >= (16 << 20):
+                            for l in sorted(self._wred):
+                                self._flush_wred(l)
+                            self.bwd.lane = lane
+                            self.bucket_marks.append((len(self.bwd), crec.prefix))
+                    else:
+                        if self.wlane:
+                            self.bwd.sync(self.wlane, 0)    # this bucket's weight gradients are complete
+                        self.bucket_marks.append((len(self.bwd), crec.prefix))
+        if self.batch_wred:
+            for l in sorted(self._wred):
+                self._flush_wred(l)
+            self.bwd.lane = 0
+            self._upload_wred_tables()
+
+    def _flush_wred(self, lane):
+        ents = self._wred.pop(lane, None)
+        if not ents:
+            return
+        block = 0
+        for e in ents:
+            e['block0'] = block
+            block += (e['Cout'] * e['Cin'] * e['ks'] * e['ks'] + 63) // 64
+        keep = self.bwd.lane
+        self.bwd.lane = lane
+        i = self.bwd.add(C.OP_WGRAD_REDUCE_TABLE, ints=(len(ents), block), ptrs=(None,))
+        self.bwd.lane = keep
+        self._wred_tables.append((i, ents))
+        if lane == 0:
+            self._wred_bytes = 0
+
+    def _upload_wred_tables(self):
+        import ctypes
+        n = sum(len(e) for _, e in self._wred_tables)
+        if not n:
+            return
+        arr = (C.HrWredEnt * n)()
+        k = 0
+        starts = []
+        for i, ents in self._wred_tables:
+            starts.append((i, k))
+            for e in ents:
+                for name, val in e.items():
+                    setattr(arr[k], name, val)
+                k += 1
+        raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+        self.keep.append(table)
+        for i, k0 in starts:
+            self.bwd.ops[i].p[0] = C.ptr(table) + k0 * ctypes.sizeof(C.HrWredEnt)
 
     def _resolve_scratch(self):
         sizes = {'stats': max(self.max_stats, 1), 'slab': max(self.max_slab, 1), 'bwdpart': max(self.max_bwd_part, 1)}

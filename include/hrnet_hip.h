@@ -59,7 +59,8 @@ enum {
   HR_OP_FILL = 16,
   HR_OP_PACK_TABLE = 17,
   HR_OP_EVENT_RECORD = 18, /* p[0] = event, recorded on the op's lane */
-  HR_OP_STREAM_WAIT = 19   /* p[0] = event, the op's lane waits for it */
+  HR_OP_STREAM_WAIT = 19,  /* p[0] = event, the op's lane waits for it */
+  HR_OP_WGRAD_REDUCE_TABLE = 20 /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -160,6 +161,17 @@ typedef struct HrPackEnt {
 } HrPackEnt;
 int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n, int total_blocks,
                              hr_stream_t stream);
+
+/* hrnet_wgrad_reduce for many convolutions in ONE launch (each layer keeps its own slab region):
+ * `table` is a DEVICE array of n entries; entry e covers blocks [block0, block0 +
+ * ceil(Cout*Cin*ks*ks / 64)); total_blocks = their sum. Same element order and summation tree as
+ * hrnet_wgrad_reduce, so the result is bit-identical to the per-layer call. */
+typedef struct HrWredEnt {
+  const float* slabs; /* [nsplit][Cout_pad][taps][Cin_pad] (kflat: [nsplit][Cout_pad][Cin_pad]) */
+  float* grad;        /* OIHW f32 [Cout][Cin][ks][ks] */
+  int32_t nsplit, Cout_pad, Cin_pad, ks, Cout, Cin, kflat, accumulate, block0, reserved;
+} HrWredEnt;
+int hrnet_wgrad_reduce_table(const HrWredEnt* table, int n, int total_blocks, hr_stream_t stream);
 
 /*
  * BatchNorm2d statistics -> per-channel affine (nn.BatchNorm2d in pose_hrnet.py:34,37,66-73,
