@@ -362,26 +362,38 @@ class Plan(object):
                 a = self.conv(xs[i], cv[b + '.conv1'], 1, bn[b + '.bn1'], relu=True)
                 c = self.conv(a, cv[b + '.conv2'], 1, bn[b + '.bn2'], relu=False)
                 xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
-        self.fwd.lane = 0
-        if side:
+        # fuse-layer convolutions stay on the lane of the branch they READ (source-major): they start as
+        # soon as that branch is done, and in the backward pass every accumulation into a branch
+        # output's gradient is ordered on one lane. The sums wait for all lanes.
+        fuse_lanes = os.environ.get('HRNET_FUSE_LANES', '1') != '0'
+        if side and not fuse_lanes:
+            self.fwd.lane = 0
             self.fwd.join(side)
             self._tape(('join', side))
-        outs = []
-        for i in range(nb):
-            terms, shifts = [], []
-            for j in range(nb):
+        term_of = {}
+        for j in range(nb):
+            if fuse_lanes:
+                self.fwd.lane = j if j in side else 0
+            for i in range(nb):
                 if j == i:
-                    terms.append(xs[j]); shifts.append(0)
+                    term_of[(i, j)] = (xs[j], 0)
                 elif j > i:
                     f = '{}.fuse_layers.{}.{}'.format(pre, i, j)
-                    terms.append(self.conv(xs[j], cv[f + '.0'], 1, bn[f + '.1'], relu=False))
-                    shifts.append(j - i)
+                    term_of[(i, j)] = (self.conv(xs[j], cv[f + '.0'], 1, bn[f + '.1'], relu=False), j - i)
                 else:
                     t = xs[j]
                     for k in range(i - j):
                         f = '{}.fuse_layers.{}.{}.{}'.format(pre, i, j, k)
                         t = self.conv(t, cv[f + '.0'], 2, bn[f + '.1'], relu=(k != i - j - 1))
-                    terms.append(t); shifts.append(0)
+                    term_of[(i, j)] = (t, 0)
+        self.fwd.lane = 0
+        if side and fuse_lanes:
+            self.fwd.join(side)
+            self._tape(('join', side))
+        outs = []
+        for i in range(nb):
+            terms = [term_of[(i, j)][0] for j in range(nb)]
+            shifts = [term_of[(i, j)][1] for j in range(nb)]
             # the output-resolution term first (sum_terms sizes the output from term 0)
             order = sorted(range(nb), key=lambda q: shifts[q])
             outs.append(self.sum([terms[q] for q in order], [shifts[q] for q in order], True,
@@ -475,6 +487,10 @@ class Plan(object):
                     self.bwd.fork(e[1])
                 else:
                     self.bwd.join(e[1])
+                    # every gradient of this module (and of everything after it) is complete here
+                    nxt = next((t for t in self.tape[ti + 1:] if t[0] == 'conv'), None)
+                    if nxt is not None and self.batch_wred:
+                        self.bucket_marks.append((len(self.bwd), nxt[2].prefix))
                 in_region = e[0] == 'join'
                 continue
             if e[0] == 'cat':
