@@ -111,6 +111,7 @@ def instrumented_step(model, x, gt, criterion):
     g_hm.copy_(hm - gt).mul_(2.0 / (hm.shape[0] * hm.shape[1]))
     stats = {}
     kinds = {}
+    crit = {}
     net.prepare_grads()
     plan.bwd.set_ptr(plan.gout_op, 0, g_hm.data_ptr())
     for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
@@ -122,6 +123,27 @@ def instrumented_step(model, x, gt, criterion):
             e1.record()
             evs.append((idx, e0, e1))
         torch.cuda.synchronize()
+        # dependency-only critical path of this program: lanes advance independently, EVENT_RECORD /
+        # STREAM_WAIT ops carry the time across (every kernel at its isolated duration, unlimited GPU)
+        clock, evt, comp, evc = {}, {}, {}, {}
+        for idx, e0, e1 in evs:
+            op = prog.ops[idx]
+            lane = int(op.i[C.LANE_SLOT])
+            if int(op.kind) == C.OP_EVENT_RECORD:
+                evt[op.p[0]] = clock.get(lane, 0.0)
+                evc[op.p[0]] = dict(comp.get(lane, {}))
+            elif int(op.kind) == C.OP_STREAM_WAIT:
+                if evt.get(op.p[0], 0.0) > clock.get(lane, 0.0):
+                    clock[lane] = evt[op.p[0]]
+                    comp[lane] = dict(evc[op.p[0]])
+            else:
+                ms = e0.elapsed_time(e1)
+                clock[lane] = clock.get(lane, 0.0) + ms
+                c = comp.setdefault(lane, {})
+                c[int(op.kind)] = c.get(int(op.kind), 0.0) + ms
+        last = max(clock, key=lambda l: clock[l])
+        crit[pname + '_by_kind'] = {str(k): round(v, 2) for k, v in sorted(comp[last].items())}
+        crit[pname] = round(max(clock.values()), 3)
         for idx, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             key = (pname, idx)
@@ -132,6 +154,7 @@ def instrumented_step(model, x, gt, criterion):
             k = kinds.setdefault(int(prog.ops[idx].kind), [0, 0.0])
             k[0] += 1; k[1] += ms
     net.mark_weights_dirty()
+    kinds['critical_path_ms'] = crit
     return stats, kinds
 
 
@@ -265,6 +288,7 @@ def main():
             'algorithmic_gflop_per_img': round(mfma_fl / args.batch / 1e9, 2)}
         extra_out['kernel_ms'] = {k: [v[0], round(v[1], 3)] for k, v in
                                   sorted(stats.items(), key=lambda kv: -kv[1][1])}
+        extra_out['critical_path_ms'] = kinds.pop('critical_path_ms')
         extra_out['op_kind_ms'] = {str(k): [v[0], round(v[1], 3)] for k, v in sorted(kinds.items())}
 
     cpu = None
