@@ -158,7 +158,7 @@ def instrumented_step(model, x, gt, criterion):
     return stats, kinds
 
 
-def cpu_baseline(sd, extra, budget_s=20.0):
+def cpu_baseline(sd, extra, budget_s=12.0):
     from hipnet import synth
     from oracle import hrnet_cpu as O
     # the box's CPU share, not the host's core count (a one-GPU box gets 16 cores)
@@ -186,7 +186,7 @@ def cpu_baseline(sd, extra, budget_s=20.0):
     while True:
         step()
         n += 1
-        if time.perf_counter() - t0 >= budget_s or n >= 12:
+        if time.perf_counter() - t0 >= budget_s or n >= 60:
             break
     dt = time.perf_counter() - t0
     return {'value': round(4 * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',

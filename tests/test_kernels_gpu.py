@@ -135,6 +135,35 @@ def test_conv2d_weight_gradient(dtype, case):
     assert hh.rel_err(got, w.grad) <= 2 * TOL[dtype]
 
 
+def test_batched_slab_sum_is_bit_identical_to_per_layer_calls():
+    """hrnet_wgrad_reduce_table (one launch for several layers) == hrnet_wgrad_reduce per layer"""
+    import ctypes
+    from hipnet import _capi as C
+    d = 'cuda:0'
+    g = torch.Generator(device=d).manual_seed(5)
+    layers = [(7, 32, 32, 3, 32, 32, 0), (130, 64, 64, 3, 64, 48, 0), (5, 32, 32, 1, 21, 32, 0), (3, 64, 32, 3, 64, 3, 1)]
+    ents = (C.HrWredEnt * len(layers))()
+    keep, want, got = [], [], []
+    block = 0
+    for e, (ns, cop, cip, ks, co, ci, kflat) in zip(ents, layers):
+        taps = ks * ks
+        slabs = torch.randn(ns, cop, 1 if kflat else taps, cip, device=d, generator=g)
+        ref = torch.randn(co, ci, ks, ks, device=d, generator=g)
+        out = ref.clone()
+        C.call('hrnet_wgrad_reduce', slabs.data_ptr(), ref.data_ptr(), ns, cop, cip, ks, co, ci, kflat, 1, C.stream_ptr())
+        e.slabs, e.grad = slabs.data_ptr(), out.data_ptr()
+        e.nsplit, e.Cout_pad, e.Cin_pad, e.ks, e.Cout, e.Cin, e.kflat, e.accumulate = ns, cop, cip, ks, co, ci, kflat, 1
+        e.block0 = block
+        block += (co * ci * taps + 63) // 64
+        keep.append(slabs); want.append(ref); got.append(out)
+    raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(d)
+    C.call('hrnet_wgrad_reduce_table', table.data_ptr(), len(layers), block, C.stream_ptr())
+    torch.cuda.synchronize()
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem_im2col_conv_and_wgrad(dtype):
     hh = _h()
