@@ -198,6 +198,53 @@ def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
 
+def infer_main(args, model, x, world, rank, dev):
+    """config 2: eval-mode forward + decode of a resident batch (replicas only: no collective)"""
+    from utils.heatmap_decoding import get_final_preds
+    model.eval()
+
+    def step():
+        with torch.no_grad():
+            hm, _ = model(x)
+            return get_final_preds(hm, use_softmax=False)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = value * 22.584 / 1e3          # forward GFLOP / image, BASELINE.md section 2
+        print(json.dumps({
+            'metric': 'images/sec forward+decode pose_hrnet_w32 256x256 bs={}/GPU'.format(args.batch),
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'pose_hrnet_w32 256x256 {} eval forward + arg-max decode, batch {}/GPU, synthetic '
+                                   'RHD-shaped crops, random-init weights'.format(args.dtype, args.batch),
+                       'global_batch': world * args.batch, 'parallelism': 'replicas{}'.format(world)},
+            'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(ach / peak, 5), 'traffic': None, 'kernel': 'whole forward pass'},
+            'cpu_baseline': None, 'preds_checksum': float(preds.sum().item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -205,6 +252,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'],
+                    help='train = the headline step (default); infer = BASELINE.json config 2: eval forward + '
+                         'arg-max decode (use with --dtype fp32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -234,6 +284,9 @@ def main():
     if world > 1:
         sync = GradSync(model)
         opt.grad_scale = 1.0 / world
+
+    if args.mode == 'infer':
+        return infer_main(args, model, x, world, rank, dev)
 
     def step():
         opt.zero_grad()

@@ -278,6 +278,32 @@ def test_w48_non_square_forward_matches_oracle():
     assert np.abs(hm.cpu().numpy() - ref_hm.numpy()).max() <= 1e-3 * max(1.0, np.abs(ref_hm.numpy()).max())
 
 
+def test_w48_training_step_matches_oracle_fp64():
+    """config 4 channels (48/96/192/384: Cin not a multiple of the K chunk, 720-wide head), non-square
+    192x160 crops, B=2, fp32 device path: loss, heat maps and every gradient in the fp32 oracle's band."""
+    from hipnet import synth
+    from oracle import hrnet_cpu as O
+    model, cfg, sd = make_model('fp32', 8, yaml=YAML48)
+    extra = dict(O.W32_EXTRA)
+    for s_, ch in ((2, [48, 96]), (3, [48, 96, 192]), (4, [48, 96, 192, 384])):
+        extra['STAGE{}'.format(s_)] = dict(O.W32_EXTRA['STAGE{}'.format(s_)], NUM_CHANNELS=ch)
+    b = synth.rhd_batch(2, seed=17, img_h=192, img_w=160)
+    r64 = _run_oracle(sd, extra, b, torch.float64)
+    r32 = _run_oracle(sd, extra, b, torch.float32)
+    hm, inter, loss = _run_hip(model, b)
+    assert hm.shape == (2, 21, 48, 40)
+    assert (hm.double() - r64['hm']).abs().max().item() <= 1e-3
+    assert abs(loss - r64['loss']) <= 1e-5 * abs(r64['loss'])
+    e_hip, e_o32, cos = _grad_errors(model, r64, r32)
+    # direction: held to the fp32 oracle's own deviation from fp64 (B=2 is more chaotic than B=4)
+    num = sum(float((r32['grads'][k] * r64['grads'][k]).sum()) for k in r64['grads'])
+    den = np.sqrt(sum(float((r32['grads'][k] ** 2).sum()) for k in r64['grads']) *
+                  sum(float((r64['grads'][k] ** 2).sum()) for k in r64['grads']))
+    assert 1.0 - cos <= 4 * (1.0 - num / den) + 1e-4, (cos, num / den)
+    assert np.median(e_hip) <= 4 * np.median(e_o32) + 1e-4, (np.median(e_hip), np.median(e_o32))
+    assert e_hip.max() <= max(0.25, 4 * e_o32.max()), (e_hip.max(), e_o32.max())
+
+
 def test_cpu_input_or_missing_library_fails_loudly():
     model, _, _ = make_model('fp32', 0)
     with pytest.raises(RuntimeError, match='no CPU path'):
