@@ -33,7 +33,7 @@ for p in (REPO, os.path.join(PKG, 'lib')):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-GFLOP_PER_IMG = {'w32': 67.70}      # fwd+bwd conv FLOPs / image, BASELINE.md section 2
+GFLOP_PER_IMG = {'w32': 67.70, 'w48': 236.5}      # fwd+bwd conv FLOPs / image, BASELINE.md section 2
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
 
 
@@ -252,6 +252,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--arch', default='w32', choices=['w32', 'w48'],
+                    help='w48 = BASELINE.json config 4: pose_hrnet_w48 384x288 (use --batch 32)')
     ap.add_argument('--mode', default='train', choices=['train', 'infer'],
                     help='train = the headline step (default); infer = BASELINE.json config 2: eval forward + '
                          'arg-max decode (use with --dtype fp32)')
@@ -273,9 +275,11 @@ def main():
     from hipnet.optim import FlatAdam, GradSync
     from oracle import hrnet_cpu as O    # cpu_baseline leg only
 
-    model, cfg, sd = build_model(args.dtype, 'RHD_HRNet_w32_max_hmloss_v1.yaml')
+    yaml_name = 'RHD_HRNet_w32_max_hmloss_v1.yaml' if args.arch == 'w32' else 'RHD_HRNet_w48_softmax_hm-pose2dloss_v1.yaml'
+    img_h, img_w = (256, 256) if args.arch == 'w32' else (384, 288)
+    model, cfg, sd = build_model(args.dtype, yaml_name)
     model = model.to(dev).train()
-    b = synth.rhd_batch(args.batch, seed=1234 + rank)
+    b = synth.rhd_batch(args.batch, seed=1234 + rank, img_h=img_h, img_w=img_w)
     x = torch.from_numpy(b['imgs']).to(dev)
     gt = torch.from_numpy(b['heatmaps']).to(dev)
     criterion = HeatmapLoss()
@@ -353,14 +357,15 @@ def main():
         imgs = world * args.batch * args.steps
         value = imgs / dt
         out = {
-            'metric': 'images/sec fwd+bwd pose_hrnet_w32 256x256 bs=64/GPU',
+            'metric': 'images/sec fwd+bwd pose_hrnet_{} {}x{} bs={}/GPU'.format(args.arch, img_h, img_w, args.batch),
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'pose_hrnet_w32 256x256 {} fwd+HeatmapLoss+bwd+Adam training step, batch {}/GPU, '
-                                   'synthetic RHD-shaped crops, random-init weights'.format(args.dtype, args.batch),
+            'config': {'workload': 'pose_hrnet_{} {}x{} {} fwd+HeatmapLoss+bwd+Adam training step, batch {}/GPU, '
+                                   'synthetic RHD-shaped crops, random-init weights'.format(
+                                       args.arch, img_h, img_w, args.dtype, args.batch),
                        'global_batch': world * args.batch, 'parallelism': 'dp{}'.format(world)},
-            'step_mfma_frac': round(value * GFLOP_PER_IMG['w32'] / 1e3 / (world * PEAK_TFLOPS[args.dtype]), 5),
+            'step_mfma_frac': round(value * GFLOP_PER_IMG[args.arch] / 1e3 / (world * PEAK_TFLOPS[args.dtype]), 5),
             'final_loss': final_loss,
             'roofline': roof, 'cpu_baseline': cpu,
         }
