@@ -278,3 +278,45 @@ def state_template(extra=W32_EXTRA, num_joints=21):
     conv('last_layer.0', tot, tot, 1, bias=True); bn('last_layer.1', tot)
     conv('last_layer.3', num_joints, tot, extra.get('FINAL_CONV_KERNEL', 1), bias=True)
     return t
+
+
+def final_preds_oracle(post_process, batch_heatmaps, center, scale):
+    """lib/core/inference.py:49-85 restated in numpy loops; the image-space map is solved from the three
+    point pairs of lib/utils/transforms.py:58-90 (what cv2.getAffineTransform computes), rot = 0."""
+    import numpy as np
+    b, k, h, w = batch_heatmaps.shape
+    flat = batch_heatmaps.reshape(b, k, -1)
+    idx = flat.argmax(2)
+    maxvals = flat.max(2).reshape(b, k, 1)
+    coords = np.zeros((b, k, 2), dtype=np.float32)
+    coords[..., 0] = idx % w
+    coords[..., 1] = np.floor(idx / w)
+    coords *= (maxvals > 0.0).astype(np.float32)
+    if post_process:
+        for n in range(b):
+            for p in range(k):
+                hm = batch_heatmaps[n][p]
+                px = int(np.floor(coords[n][p][0] + 0.5))
+                py = int(np.floor(coords[n][p][1] + 0.5))
+                if 1 < px < w - 1 and 1 < py < h - 1:
+                    diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
+                    coords[n][p] += np.sign(diff) * .25
+    preds = coords.copy()
+    for i in range(b):
+        sc = np.asarray(scale[i], dtype=np.float32) * 200.0
+        src_w = sc[0]
+        src = np.zeros((3, 2), dtype=np.float32)
+        dst = np.zeros((3, 2), dtype=np.float32)
+        src[0] = center[i]
+        src[1] = np.asarray(center[i], dtype=np.float32) + np.array([0, src_w * -0.5], np.float32)
+        dst[0] = [w * 0.5, h * 0.5]
+        dst[1] = np.array([w * 0.5, h * 0.5], np.float32) + np.array([0, w * -0.5], np.float32)
+        for pts in (src, dst):
+            d = pts[0] - pts[1]
+            pts[2] = pts[1] + np.array([-d[1], d[0]], dtype=np.float32)
+        # affine t with t @ [x, y, 1] = src for the three dst points
+        a = np.concatenate([dst.astype(np.float64), np.ones((3, 1))], axis=1)
+        t = np.linalg.solve(a, src.astype(np.float64)).T          # 2 x 3
+        for p in range(k):
+            preds[i, p] = t @ np.array([coords[i, p, 0], coords[i, p, 1], 1.0])
+    return preds, maxvals

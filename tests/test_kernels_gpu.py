@@ -478,6 +478,26 @@ def test_losses_and_decode_against_oracle(golden_dir):
     assert hh.rel_err(dh.cpu(), hr.grad) <= 1e-6
 
 
+def test_final_preds_with_post_process_and_image_space_map():
+    """core.inference.get_final_preds (reference lib/core/inference.py:49-85) vs the looped restatement"""
+    from config import get_cfg_defaults
+    from core.inference import get_final_preds
+    from oracle import hrnet_cpu as O
+    rng = np.random.default_rng(3)
+    hms = rng.random((3, 21, 24, 20)).astype(np.float32)
+    hms[0, 0] = 0.0                                   # all-zero map: prediction zeroed
+    hms[1, 2, 0, 5] = 2.0                             # border maximum: no refinement
+    center = rng.random((3, 2)).astype(np.float32) * 100 + 50
+    scale = rng.random((3, 2)).astype(np.float32) + 0.5
+    for pp in (False, True):
+        cfg = get_cfg_defaults()
+        cfg.TEST.POST_PROCESS = pp
+        got, gmax = get_final_preds(cfg, hms, center, scale)
+        want, wmax = O.final_preds_oracle(pp, hms, center, scale)
+        assert np.array_equal(gmax, wmax)
+        assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
+
+
 def test_adam_step_matches_torch():
     hh = _h()
     from hipnet import _capi as C
