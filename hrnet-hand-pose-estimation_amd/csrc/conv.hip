@@ -43,6 +43,7 @@ struct ConvArgs {
   int Hz, Wz;        // logical input extent (== H, W unless upz)
   int Ho, Wo, Cout;
   int tiles_y, tiles_x, total_tiles, tpw;  // tpw = pixel tiles per workgroup
+  int gx, gy;                              // pixel walks x output-channel blocks (1-D grid, see conv_body)
   int in_relu, upz, accumulate;
 };
 
@@ -99,11 +100,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   const int wc = wave / WP;
   const int li = lane & 15;
   const int lg = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // 1-D grid, XCD-aware: workgroup ids round-robin over the 8 XCDs, so the gy output-channel blocks of one
+  // pixel walk get ids 8 apart - the same XCD (they share its L2 for the input tile) and adjacent in time
+  int wg_p, wg_nb;
+  if (a.gy == 1) {
+    wg_p = blockIdx.x; wg_nb = 0;
+  } else {
+    const int grp = blockIdx.x / (8 * a.gy), r = blockIdx.x % (8 * a.gy);
+    wg_nb = r / 8;
+    wg_p = grp * 8 + (r & 7);
+  }
+  if (wg_p >= a.gx) return;
+  const int n0 = wg_nb * BN;
   constexpr int PAD = KS / 2;
 
   const int nch = (a.Cin + C::KC - 1) / C::KC;
-  const int tile0 = blockIdx.x * a.tpw;
+  const int tile0 = wg_p * a.tpw;
   const int ntile = min(a.tpw, a.total_tiles - tile0);
   const int nstage = ntile * nch;
   const bool wres = nch == 1;  // weights stay resident in LDS
@@ -331,7 +343,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   }
 
 #ifdef HR_STAMP
-  unsigned long long* stamp_buf = (unsigned long long*)a.stats + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32;
+  unsigned long long* stamp_buf = (unsigned long long*)a.stats + (size_t)blockIdx.x * 32;
   int stamp_i = 0;
 #define STAMP() do { if (tid == 0 && stamp_i < 32) stamp_buf[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -487,7 +499,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 #pragma unroll
       for (int q = 0; q < WP; ++q) s += sl[(q * 2 + which) * BN + cl];
       if (n0 + cl < a.Cout)
-        a.stats[((size_t)blockIdx.x * 2 + which) * a.Cout + n0 + cl] = s;
+        a.stats[((size_t)wg_p * 2 + which) * a.Cout + n0 + cl] = s;
     }
   }
 }
@@ -557,7 +569,8 @@ inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
 
 template <typename T, int KS, int STRIDE, int KM>
 int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
-  dim3 grid((unsigned)tc.gx, (unsigned)((a.Cout + tc.bn - 1) / tc.bn));
+  const int gy_ = (a.Cout + tc.bn - 1) / tc.bn;
+  dim3 grid((unsigned)(gy_ == 1 ? tc.gx : (tc.gx + 7) / 8 * 8 * gy_));
   switch (tc.id) {
     case 0:   // (stride-2 convs only use the 8x8 tiles: their halo is (2*T+1)^2)
       if constexpr (STRIDE == 1)
@@ -652,6 +665,8 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.tiles_x = (Wo + tc.tw - 1) / tc.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.tpw = tc.tpw;
+  a.gx = tc.gx;
+  a.gy = (Cout + tc.bn - 1) / tc.bn;
   // the tile choice is keyed on the ORIGINAL stride so hrnet_conv_tiles() agrees; a upz conv
   // runs the stride-1 kernel with that tile
   if (dtype == HR_F32) return launch_t<float>(a, tc, N, ks, stride, s);
