@@ -232,10 +232,11 @@ static void fill_cat(HrOp& op, int dtype, const int* hs, const int* ws, const in
 
 extern "C" int hrnet_bilinear_cat(int dtype, void* cat, const void* const* xs, const int* hs,
                                   const int* ws, const int* cs, int nbr, int N, int H, int W,
-                                  hr_stream_t stream) {
+                                  int align_corners, hr_stream_t stream) {
   OP_BEGIN(HR_OP_BILINEAR_CAT);
   HR_REQUIRE(nbr >= 1 && nbr <= 4 && xs && hs && ws && cs, "bilinear_cat: args");
   fill_cat(op, dtype, hs, ws, cs, nbr, N, H, W);
+  op.f[0] = align_corners ? 1.f : 0.f;
   op.p[0] = cat;
   for (int k = 0; k < nbr; ++k) op.p[1 + k] = (void*)xs[k];
   return hr_launch_bilinear_cat(op, (hipStream_t)stream);
@@ -243,10 +244,11 @@ extern "C" int hrnet_bilinear_cat(int dtype, void* cat, const void* const* xs, c
 
 extern "C" int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const int* hs,
                                       const int* ws, const int* cs, int nbr, int N, int H, int W,
-                                      int accumulate, hr_stream_t stream) {
+                                      int align_corners, int accumulate, hr_stream_t stream) {
   OP_BEGIN(HR_OP_BILINEAR_CAT_BWD);
   HR_REQUIRE(nbr >= 1 && nbr <= 4 && dxs && hs && ws && cs, "bilinear_cat_bwd: args");
   fill_cat(op, dtype, hs, ws, cs, nbr, N, H, W);
+  op.f[0] = align_corners ? 1.f : 0.f;
   op.i[17] = accumulate;
   op.p[0] = (void*)dcat;
   for (int k = 0; k < nbr; ++k) op.p[1 + k] = dxs[k];

@@ -325,14 +325,23 @@ struct CatArgs {
   char* xs[4];
   int hs[4], ws[4], cs[4], coff[4];
   int nbr, N, H, W, Ctot, accumulate;
+  int align;   // align_corners=True (pose_hrnet_softmax.py:499-501) instead of False (pose_hrnet.py:560-562)
 };
 
-__device__ __forceinline__ void bilin_src(int d, int in_size, int out_size, int& i0, int& i1, float& l1) {
-  // PyTorch area_pixel_compute_source_index(align_corners=False): src = (d+0.5)*scale-0.5, clamp >= 0
-  const float scale = (float)in_size / (float)out_size;
-  float src = ((float)d + 0.5f) * scale - 0.5f;
-  if (src < 0.f) src = 0.f;
+__device__ __forceinline__ void bilin_src(int d, int in_size, int out_size, int align, int& i0, int& i1,
+                                          float& l1) {
+  float src;
+  if (align) {
+    // PyTorch area_pixel_compute_source_index(align_corners=True): src = d * (in-1)/(out-1)
+    src = out_size > 1 ? (float)d * ((float)(in_size - 1) / (float)(out_size - 1)) : 0.f;
+  } else {
+    // align_corners=False: src = (d+0.5)*scale-0.5, clamp >= 0
+    const float scale = (float)in_size / (float)out_size;
+    src = ((float)d + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
   i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
   i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
   l1 = src - (float)i0;
 }
@@ -364,8 +373,8 @@ __global__ __launch_bounds__(256) void bilinear_cat_kernel(CatArgs a) {
     } else {
       int y0, y1, x0, x1;
       float ly, lx;
-      bilin_src(oy, hs, a.H, y0, y1, ly);
-      bilin_src(ox, ws, a.W, x0, x1, lx);
+      bilin_src(oy, hs, a.H, a.align, y0, y1, ly);
+      bilin_src(ox, ws, a.W, a.align, x0, x1, lx);
       float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
       const size_t base = (size_t)n * hs * ws;
       v16_unpack<T>(*(const V16*)(src + ((base + (size_t)y0 * ws + x0) * cs + cl) * sizeof(T)), f00);
@@ -414,13 +423,13 @@ __global__ __launch_bounds__(256) void bilinear_cat_bwd_kernel(CatArgs a, int b)
       for (int dy = dy0; dy < dy1; ++dy) {
         int y0, y1;
         float ly;
-        bilin_src(dy, hs, a.H, y0, y1, ly);
+        bilin_src(dy, hs, a.H, a.align, y0, y1, ly);
         const float wy = (y0 == sy ? 1.f - ly : 0.f) + (y1 == sy ? ly : 0.f);
         if (wy == 0.f) continue;
         for (int dx = dx0; dx < dx1; ++dx) {
           int x0, x1;
           float lx;
-          bilin_src(dx, ws, a.W, x0, x1, lx);
+          bilin_src(dx, ws, a.W, a.align, x0, x1, lx);
           const float wx = (x0 == sx ? 1.f - lx : 0.f) + (x1 == sx ? lx : 0.f);
           if (wx == 0.f) continue;
           float gv[VEC];
@@ -818,6 +827,7 @@ static int fill_cat_args(const HrOp& op, CatArgs& a, bool bwd) {
   }
   a.Ctot = off;
   a.accumulate = bwd ? op.i[17] : 0;
+  a.align = op.f[0] != 0.f;   // (all integer slots are taken)
   return 0;
 }
 

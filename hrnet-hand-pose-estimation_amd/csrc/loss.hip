@@ -16,6 +16,57 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, red[k]);
+  __syncthreads();
+  return m;
+}
+
+// spatial softmax with temperature, one block per (batch, joint) map (pose_hrnet_softmax.py:520-524)
+__global__ __launch_bounds__(256) void spatial_softmax_fwd_kernel(const float* x, const float* temp, float* out,
+                                                                  int HW) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * HW;
+  const float t = temp[0];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, x[base + i] * t);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float e = expf(x[base + i] * t - m);
+    out[base + i] = e;
+    s += e;
+  }
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+  for (int i = threadIdx.x; i < HW; i += 256) out[base + i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const float* x, const float* out,
+                                                                  const float* gout, const float* temp, float* dx,
+                                                                  float* dtemp_partial, int HW) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * HW;
+  const float t = temp[0];
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) dot = fmaf(gout[base + i], out[base + i], dot);
+  dot = block_sum(dot, red);
+  float dt = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float dz = out[base + i] * (gout[base + i] - dot);
+    dx[base + i] = t * dz;
+    dt = fmaf(dz, x[base + i], dt);
+  }
+  dt = block_sum(dt, red);
+  if (threadIdx.x == 0) dtemp_partial[blockIdx.x] = dt;
+}
+
 // per-map sum of (pred-gt)^2 or |pred-gt|
 __global__ __launch_bounds__(256) void hm_loss_map_kernel(const float* pred, const float* gt,
                                                           float* partial, int HW, int mode) {
@@ -207,6 +258,21 @@ extern "C" int hrnet_heatmap_loss_bwd(const float* pred, const float* gt, const 
   hipLaunchKernelGGL(hm_loss_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, pred, gt,
                      gout, dpred, n, 1.0f / (float)BK, mode);
   return hr_check_launch("heatmap_loss_bwd");
+}
+
+extern "C" int hrnet_spatial_softmax_fwd(const float* x, const float* temp, float* out, int BK, int HW,
+                                         hr_stream_t stream) {
+  HR_REQUIRE(x && temp && out && BK > 0 && HW > 0, "spatial_softmax_fwd: args");
+  hipLaunchKernelGGL(spatial_softmax_fwd_kernel, dim3(BK), dim3(256), 0, (hipStream_t)stream, x, temp, out, HW);
+  return hr_check_launch("spatial_softmax_fwd");
+}
+
+extern "C" int hrnet_spatial_softmax_bwd(const float* x, const float* out, const float* gout, const float* temp,
+                                         float* dx, float* dtemp_partial, int BK, int HW, hr_stream_t stream) {
+  HR_REQUIRE(x && out && gout && temp && dx && dtemp_partial && BK > 0 && HW > 0, "spatial_softmax_bwd: args");
+  hipLaunchKernelGGL(spatial_softmax_bwd_kernel, dim3(BK), dim3(256), 0, (hipStream_t)stream, x, out, gout, temp,
+                     dx, dtemp_partial, HW);
+  return hr_check_launch("spatial_softmax_bwd");
 }
 
 extern "C" int hrnet_decode_expectation(const float* hms, float* preds, int BK, int H, int W,

@@ -80,7 +80,10 @@ def _to_device(t, device):
 
 def _forward_and_losses(config, ret, model, recorder, device):
     imgs, heatmaps_gt, pose2d_gt, visibility = ret['imgs'], ret['heatmaps'], ret['pose2d'], ret['visibility']
-    heatmaps_pred, _inter = model(_to_device(imgs, device))
+    # pose_hrnet returns (heatmaps, inter_feat); pose_hrnet_softmax adds the temperature as a third item
+    # (the reference's 2-tuple unpack at lib/core/function.py:68 cannot take that model)
+    outputs = model(_to_device(imgs, device))
+    heatmaps_pred = outputs[0]
     pose2d_pred = get_final_preds(heatmaps_pred, use_softmax=config.MODEL.HEATMAP_SOFTMAX)
     if config.LOSS.WITH_HEATMAP_LOSS:
         heatmaps_gt = _to_device(heatmaps_gt, device)

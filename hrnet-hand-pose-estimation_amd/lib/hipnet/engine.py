@@ -270,7 +270,7 @@ class Plan(object):
         self._tape(('sum', list(terms), list(shifts), relu_out, out))
         return Val(out)
 
-    def bilinear_cat(self, vals, name):
+    def bilinear_cat(self, vals, name, align=False):
         a0 = vals[0].act
         ctot = sum(v.act.C for v in vals)
         cat = self._act(name, a0.N, a0.H, a0.W, ctot)
@@ -278,11 +278,11 @@ class Plan(object):
         ws = [v.act.W for v in vals] + [0] * (4 - len(vals))
         cs = [v.act.C for v in vals] + [0] * (4 - len(vals))
         self.fwd.add(C.OP_BILINEAR_CAT, ints=[self.dtid, len(vals), a0.N, a0.H, a0.W] + hs + ws + cs,
-                     ptrs=[C.ptr(cat.t)] + [C.ptr(v.act.t) for v in vals])
+                     floats=(1.0 if align else 0.0,), ptrs=[C.ptr(cat.t)] + [C.ptr(v.act.t) for v in vals])
         for v in vals:
             assert v.bn is None and not v.relu
             v.act.nuse += 1
-        self._tape(('cat', list(vals), cat))
+        self._tape(('cat', list(vals), cat, align))
         return Val(cat)
 
     # ---- network walk (reference: PoseHighResolutionNet.forward, pose_hrnet.py:511-568) ----
@@ -335,7 +335,10 @@ class Plan(object):
             ys = xs
             if s == 3:
                 inter = ys[0]
-        cat = self.bilinear_cat(ys, 'head.cat')
+        # pose_hrnet_softmax (lib/models/pose_hrnet_softmax.py:499-506): align_corners=True, inter_feat = the concat
+        cat = self.bilinear_cat(ys, 'head.cat', align=bool(getattr(net.module, 'head_align_corners', False)))
+        if getattr(net.module, 'inter_from_cat', False):
+            inter = cat
         h = self.conv(cat, cv['last_layer.0'], 1, bn['last_layer.1'], relu=True)
         out = self.conv(h, cv['last_layer.3'], 1, None, relu=False)
         self.out_act, self.inter_act = out.act, inter.act
@@ -503,13 +506,16 @@ class Plan(object):
                 in_region = e[0] == 'join'
                 continue
             if e[0] == 'cat':
-                _, vals, cat = e
+                _, vals, cat, align = e
+                if cat is self.inter_act and self.inter_gop is None:
+                    self.inter_gop = len(self.bwd)     # optional external gradient of inter_feat joins here
                 hs = [v.act.H for v in vals] + [0] * (4 - len(vals))
                 ws = [v.act.W for v in vals] + [0] * (4 - len(vals))
                 cs = [v.act.C for v in vals] + [0] * (4 - len(vals))
                 assert not any(v.act.ginit for v in vals)
                 self.bwd.add(C.OP_BILINEAR_CAT_BWD,
                              ints=[self.dtid, len(vals), cat.N, cat.H, cat.W] + hs + ws + cs + [0],
+                             floats=(1.0 if align else 0.0,),
                              ptrs=[C.ptr(cat.g)] + [C.ptr(v.act.g) for v in vals])
                 for v in vals:
                     v.act.ginit = True

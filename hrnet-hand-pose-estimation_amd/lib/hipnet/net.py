@@ -26,6 +26,10 @@ class HipNet(object):
 
     # ---- flat master parameters / gradients --------------------------------------------------
     def _flatten(self, params):
+        # frozen parameters (requires_grad=False, e.g. a fixed softmax temperature) sit behind the trainable
+        # ones so that the fused optimiser kernel covers exactly [0, trainable_count)
+        params = [p for p in params if p.requires_grad] + [p for p in params if not p.requires_grad]
+        self.trainable_count = sum(p.numel() for p in params if p.requires_grad)
         total = sum(p.numel() for p in params)
         self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -128,18 +132,23 @@ class HipNet(object):
         return hm, inter, plan
 
     def prepare_grads(self):
-        """PyTorch semantics for .grad: None -> fresh, ours -> accumulate."""
-        none = [p.grad is None for p in self.params]
-        if all(none):
+        """PyTorch semantics for .grad: None -> fresh, ours -> accumulate, a foreign tensor (autograd
+        reached a parameter outside the recorded programs first, e.g. the softmax temperature) ->
+        adopted into the flat buffer."""
+        ours = [p.grad is not None and p.grad.data_ptr() == self._gview[id(p)].data_ptr() for p in self.params]
+        if not any(ours):
+            foreign = [(p, p.grad) for p in self.params if p.grad is not None]
             self.flat_g.zero_()
+            for p, g in foreign:
+                self._gview[id(p)].copy_(g)
             for p in self.params:
                 p.grad = self._gview[id(p)]
             return
-        for p in self.params:
+        for p, mine in zip(self.params, ours):
             if p.grad is None:
                 self._gview[id(p)].zero_()
                 p.grad = self._gview[id(p)]
-            elif p.grad.data_ptr() != self._gview[id(p)].data_ptr():
+            elif not mine:
                 self._gview[id(p)].copy_(p.grad)
                 p.grad = self._gview[id(p)]
 

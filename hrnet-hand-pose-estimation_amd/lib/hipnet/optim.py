@@ -43,7 +43,7 @@ class FlatAdam(object):
         self.step_count += 1
         lr = self.param_groups[0]['lr']
         C.call('hrnet_adam_step', net.flat_p.data_ptr(), net.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-               self.exp_avg_sq.data_ptr(), net.total_params, lr, self.betas[0], self.betas[1], self.eps,
+               self.exp_avg_sq.data_ptr(), net.trainable_count, lr, self.betas[0], self.betas[1], self.eps,
                self.weight_decay, self.step_count, self.grad_scale, C.stream_ptr())
         net.mark_weights_dirty()
 

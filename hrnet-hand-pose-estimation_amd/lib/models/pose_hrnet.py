@@ -123,6 +123,9 @@ class PoseHighResolutionNet(nn.Module):
 
     def __init__(self, cfg, **kwargs):
         super(PoseHighResolutionNet, self).__init__()
+        self._build(cfg, **kwargs)
+
+    def _build(self, cfg, **kwargs):
         extra = cfg.MODEL.EXTRA
         self.conv1 = _conv(3, 64, 3, 2)
         self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)

@@ -59,7 +59,7 @@ def main():
             imgs = ret['imgs'].to(device)
             torch.cuda.synchronize()
             t0 = time.time()
-            hm, _ = model(imgs)
+            hm = model(imgs)[0]      # (heatmaps, inter_feat[, temperature])
             pred = get_final_preds(hm, cfg.MODEL.HEATMAP_SOFTMAX)
             torch.cuda.synchronize()
             if i >= 20 or i >= len(loader) // 2:

@@ -224,15 +224,17 @@ int hrnet_bn_bwd_finalize(const float* partials, int blocks, int C, float count,
 
 /*
  * Head input: cat[N,H,W,sum(C_j)] = [x0, bilinear(x1), bilinear(x2), bilinear(x3)]
- * (F.upsample(mode='bilinear'), align_corners=False, then torch.cat: pose_hrnet.py:560-565).
+ * (F.upsample(mode='bilinear'), align_corners=False, then torch.cat: pose_hrnet.py:560-565;
+ * align_corners=1: F.interpolate(..., align_corners=True) of pose_hrnet_softmax.py:499-503).
  * Branch j has spatial size (H>>j, W>>j) ... given explicitly. nbr <= 4.
  */
 int hrnet_bilinear_cat(int dtype, void* cat, const void* const* xs, const int* hs, const int* ws,
-                       const int* cs, int nbr, int N, int H, int W, hr_stream_t stream);
+                       const int* cs, int nbr, int N, int H, int W, int align_corners,
+                       hr_stream_t stream);
 /* dxs[j] (+)= bilinear^T(dcat[..., slice_j]) (gather form, deterministic) */
 int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const int* hs,
                            const int* ws, const int* cs, int nbr, int N, int H, int W,
-                           int accumulate, hr_stream_t stream);
+                           int align_corners, int accumulate, hr_stream_t stream);
 
 /* stem: NCHW f32 image -> im2col rows [N,Ho,Wo,Kpad] (k = (r*3+s)*C + c), 3x3 stride 2 pad 1
  * (conv1, pose_hrnet.py:283-284,512). */
@@ -274,6 +276,17 @@ int hrnet_decode_expectation_bwd(const float* gpreds, float* dhms, int BK, int H
                                  int accumulate, hr_stream_t stream);
 int hrnet_decode_argmax(const float* hms, float* preds, float* maxvals, int BK, int H, int W,
                         int inference_style, hr_stream_t stream);
+
+/*
+ * Spatial softmax head of pose_hrnet_softmax (lib/models/pose_hrnet_softmax.py:520-524):
+ * out[bk, :] = softmax(x[bk, :] * *temp) over the HW positions of each map, NCHW f32.
+ * backward: dx = temp * out * (gout - sum(gout*out)); dtemp_partial[bk] = sum_i dz_i * x_i with
+ * dz = out * (gout - sum(gout*out)) (the caller sums the BK partials: d loss / d temperature).
+ */
+int hrnet_spatial_softmax_fwd(const float* x, const float* temp, float* out, int BK, int HW,
+                              hr_stream_t stream);
+int hrnet_spatial_softmax_bwd(const float* x, const float* out, const float* gout, const float* temp,
+                              float* dx, float* dtemp_partial, int BK, int HW, hr_stream_t stream);
 
 /*
  * JointsMSELoss (lib/core/loss.py:37-50): sum_bk ||pred-gt||_2 * vis / max(1, sum vis), or

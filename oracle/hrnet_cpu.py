@@ -121,11 +121,13 @@ def _transition(P, ys, pre, n_pre, n_cur):
     return xs
 
 
-def hrnet_forward(state, extra, x, training=False):
+def hrnet_forward(state, extra, x, training=False, softmax_head=False):
     """PoseHighResolutionNet.forward, pose_hrnet.py:511-568.
 
     state: {key: tensor}; extra: cfg.MODEL.EXTRA-like mapping with STAGE2..4.
     Returns (heatmaps, inter_feat, new_running_stats).
+    softmax_head=True: the pose_hrnet_softmax variant (pose_hrnet_softmax.py:497-528): align_corners=True
+    up-sampling, inter_feat = the concatenation, spatial softmax times state['trainable_temp'].
     """
     P = Params(state, training)
     x = F.relu(_bn(P, _conv(P, x, 'conv1', 2), 'bn1'))
@@ -144,10 +146,15 @@ def hrnet_forward(state, extra, x, training=False):
         if s == 3:
             inter_feat = ys[0]
     h, w = ys[0].shape[2], ys[0].shape[3]
-    ups = [ys[0]] + [F.interpolate(t, size=(h, w), mode='bilinear', align_corners=False) for t in ys[1:]]
+    ups = [ys[0]] + [F.interpolate(t, size=(h, w), mode='bilinear', align_corners=softmax_head) for t in ys[1:]]
     z = torch.cat(ups, 1)
+    if softmax_head:
+        inter_feat = z
     z = F.relu(_bn(P, _conv(P, z, 'last_layer.0'), 'last_layer.1'))
     z = _conv(P, z, 'last_layer.3')
+    if softmax_head:
+        flat = z.reshape(z.shape[0], z.shape[1], -1)
+        z = F.softmax(flat * state['trainable_temp'], dim=2).reshape(z.shape)
     return z, inter_feat, P.new_stats
 
 

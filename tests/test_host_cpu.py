@@ -80,6 +80,20 @@ def test_module_surface_matches_reference_state_dict():
         pose_hrnet.get_pose_net(cfg, is_train=True)
 
 
+def test_softmax_variant_module_surface():
+    from config import get_cfg_defaults
+    from models import pose_hrnet_softmax
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml'))
+    m = eval('pose_hrnet_softmax.get_pose_net')(cfg, is_train=False)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == 'trainable_temp' and len(keys) == 1840            # reference order: own parameter first
+    assert m.trainable_temp.requires_grad and float(m.trainable_temp) == 1.0
+    assert m.head_align_corners and m.inter_from_cat
+    cfg.MODEL.TRAINABLE_SOFTMAX = False
+    assert not pose_hrnet_softmax.get_pose_net(cfg, is_train=False).trainable_temp.requires_grad
+
+
 def test_init_weights_follows_reference_distribution():
     from config import get_cfg_defaults
     from models import pose_hrnet

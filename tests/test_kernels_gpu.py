@@ -356,15 +356,16 @@ def test_dgrad_epilogue_gathers_batchnorm_backward_sums(dtype, mode, case):
     assert float((got - want).abs().max()) <= 3 * TOL[dtype] * scale
 
 
+@pytest.mark.parametrize('align', [False, True])
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_bilinear_concat_forward_backward(dtype):
+def test_bilinear_concat_forward_backward(dtype, align):
     hh = _h()
     from hipnet import _capi as C
     N, H, W = 2, 16, 16
     cs = [32, 64, 128, 256]
     g = torch.Generator().manual_seed(21)
     xs = [_q(torch.randn(N, c, H >> j, W >> j, generator=g), dtype).requires_grad_(True) for j, c in enumerate(cs)]
-    ups = [xs[0]] + [F.interpolate(t, size=(H, W), mode='bilinear', align_corners=False) for t in xs[1:]]
+    ups = [xs[0]] + [F.interpolate(t, size=(H, W), mode='bilinear', align_corners=align) for t in xs[1:]]
     cat = torch.cat(ups, 1)
     gcat = _q(torch.randn(cat.shape, generator=g), dtype)
     cat.backward(gcat)
@@ -373,12 +374,12 @@ def test_bilinear_concat_forward_backward(dtype):
     out = torch.empty(N, H, W, sum(cs), dtype=dtype, device=d)
     hs, ws = [H >> j for j in range(4)], [W >> j for j in range(4)]
     C.call('hrnet_bilinear_cat', hh.dt_id(dtype), out.data_ptr(), hh.ptr_array(xd), hh.int_array(hs),
-           hh.int_array(ws), hh.int_array(cs), 4, N, H, W, C.stream_ptr())
+           hh.int_array(ws), hh.int_array(cs), 4, N, H, W, 1 if align else 0, C.stream_ptr())
     assert hh.rel_err(hh.from_nhwc(out), cat.detach()) <= TOL[dtype]
     dxs = [torch.empty_like(t) for t in xd]
     gcd = hh.nhwc(gcat, dtype)
     C.call('hrnet_bilinear_cat_bwd', hh.dt_id(dtype), gcd.data_ptr(), hh.ptr_array(dxs),
-           hh.int_array(hs), hh.int_array(ws), hh.int_array(cs), 4, N, H, W, 0, C.stream_ptr())
+           hh.int_array(hs), hh.int_array(ws), hh.int_array(cs), 4, N, H, W, 1 if align else 0, 0, C.stream_ptr())
     for t, dx in zip(xs, dxs):
         assert hh.rel_err(hh.from_nhwc(dx), t.grad) <= 2 * TOL[dtype]
 
@@ -496,6 +497,27 @@ def test_final_preds_with_post_process_and_image_space_map():
         want, wmax = O.final_preds_oracle(pp, hms, center, scale)
         assert np.array_equal(gmax, wmax)
         assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
+
+
+def test_spatial_softmax_with_temperature_forward_backward():
+    """pose_hrnet_softmax.py:520-524: softmax over each map times a (trainable) temperature"""
+    from hipnet import _capi as C
+    d = 'cuda:0'
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(3, 21, 24, 20, generator=g) * 3).requires_grad_(True)
+    temp = torch.tensor(1.7, requires_grad=True)
+    out = F.softmax(x.view(3, 21, -1) * temp, dim=2).view(x.shape)
+    gout = torch.randn(x.shape, generator=g)
+    out.backward(gout)
+    xd, td, gd = x.detach().to(d), temp.detach().to(d).reshape(1), gout.to(d)
+    od, dxd, part = torch.empty_like(xd), torch.empty_like(xd), torch.empty(63, device=d)
+    C.call('hrnet_spatial_softmax_fwd', xd.data_ptr(), td.data_ptr(), od.data_ptr(), 63, 480, C.stream_ptr())
+    C.call('hrnet_spatial_softmax_bwd', xd.data_ptr(), od.data_ptr(), gd.data_ptr(), td.data_ptr(), dxd.data_ptr(),
+           part.data_ptr(), 63, 480, C.stream_ptr())
+    assert float((od.cpu() - out.detach()).abs().max()) <= 1e-6
+    assert abs(float(od.sum()) - 63.0) <= 1e-3
+    assert float((dxd.cpu() - x.grad).abs().max()) <= 1e-5 * max(1.0, float(x.grad.abs().max()))
+    assert abs(float(part.sum()) - float(temp.grad)) <= 1e-4 * max(1.0, abs(float(temp.grad)))
 
 
 def test_adam_step_matches_torch():

@@ -116,3 +116,34 @@ def test_get_max_preds_mask():
     preds, maxvals = O.get_max_preds(hm)
     assert preds[0, 0].tolist() == [1.0, 3.0] and preds[0, 1].tolist() == [0.0, 0.0]
     assert maxvals[0, 0, 0] == 2.0 and maxvals[0, 1, 0] == -1.0
+
+
+def test_softmax_head_variant_matches_reference_fixture(golden_dir):
+    """pose_hrnet_softmax: soft-max heat maps, loss, temperature gradient and every
+    parameter gradient of the reference's own module (tests/golden/make_golden_softmax.py)."""
+    g = np.load(os.path.join(golden_dir, 'w32_softmax_train_b2.npz'))
+    sd = _state(5)
+    sd['trainable_temp'] = torch.tensor(1.5)
+    pk = [k for k in sd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    for k in pk:
+        sd[k] = sd[k].double().requires_grad_(True)
+    for k in sd:
+        if k.endswith(('running_mean', 'running_var')):
+            sd[k] = sd[k].double()
+    b = synth.rhd_batch(2, seed=321, img_h=128, img_w=128)
+    hm, inter, _ = O.hrnet_forward(sd, O.W32_EXTRA, torch.from_numpy(b['imgs']).double(), training=True,
+                                   softmax_head=True)
+    gt = torch.from_numpy(b['heatmaps']).double()
+    gt = gt / gt.sum((2, 3), keepdim=True).clamp_min(1e-6)
+    loss = O.heatmap_loss(hm, gt) * 1e4 + 1e-3 * inter.square().mean()
+    loss.backward()
+    assert tuple(inter.shape) == tuple(g['inter_shape']) == (2, 480, 32, 32)
+    assert np.abs(hm.detach().numpy() - g['heatmaps']).max() <= 2e-5      # fp64 here, fp32 fixture; maps sum to 1
+    assert abs(loss.item() - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    assert abs(sd['trainable_temp'].grad.item() - float(g['temp_grad'])) <= 2e-3 * abs(float(g['temp_grad']))
+    np.testing.assert_allclose(_checksum(inter)[:2], g['inter_feat_checksum'][:2], rtol=1e-4)
+    for k in ('last_layer.3.weight', 'stage4.2.fuse_layers.0.3.0.weight', 'conv1.weight'):
+        ref = g['grad.' + k]
+        err = np.abs(sd[k].grad.numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err <= 5e-2, (k, err)          # the fixture is fp32: the chaotic-gradient band (DESIGN 2)
+    assert list(g['state_keys_head'])[0] == 'trainable_temp'
