@@ -17,7 +17,7 @@ import torch
 
 from config import cfg, update_config
 from dataset.build import make_dataloader
-from models import pose_hrnet  # noqa: F401
+from models import pose_hrnet, pose_hrnet_softmax  # noqa: F401
 from utils.heatmap_decoding import get_final_preds
 
 

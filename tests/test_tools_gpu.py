@@ -36,3 +36,20 @@ def test_train_then_evaluate_cli(tmp_path):
                '--batch_size', '4', '--num_batches', '4', '--gpu', '0', 'OUTPUT_DIR', out], PKG)
     assert 'fps:' in ev and 'PCK@20px' in ev
     assert os.path.exists(os.path.join(out, 'eval2D_results_RHD_HRNet_w32_max_hmloss_v1', 'PCK2d.txt'))
+
+
+def test_train_cli_with_the_trainable_softmax_variant(tmp_path):
+    """pose_hrnet_softmax through tools/train.py - expectation decode + key-point loss, the
+    temperature learns (reference experiments/RHD/RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml)."""
+    cfg = os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml')
+    out = str(tmp_path / 'out')
+    log = _run([sys.executable, 'tools/train.py', '--cfg', cfg, '--batches-per-epoch', '3', 'TRAIN.BEGIN_EPOCH', '0',
+                'TRAIN.END_EPOCH', '1', 'OUTPUT_DIR', out, 'LOG_DIR', str(tmp_path / 'log'), 'TRAIN.IMAGES_PER_GPU', '4',
+                'TEST.IMAGES_PER_GPU', '4', 'PRINT_FREQ', '1'], PKG)
+    assert 'Speed' in log and 'Pose2DLoss' in log
+    exp = os.path.join(out, 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1')
+    import torch
+    sd = torch.load(os.path.join(exp, 'final_state.pth.tar'), map_location='cpu')
+    sd = sd.get('state_dict', sd)
+    key = [k for k in sd if k.endswith('trainable_temp')][0]
+    assert float(sd[key]) != 1.0          # the temperature moved
