@@ -67,6 +67,46 @@ __global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const float* x
   if (threadIdx.x == 0) dtemp_partial[blockIdx.x] = dt;
 }
 
+// Gaussian heat-map targets (reference lib/dataset/target_generators/target_generators.py:14-53): peak 1 at
+// int(coord), window [x-3s-1, x+3s+2), zero map for an invisible or out-of-range joint. One block per map.
+__global__ __launch_bounds__(256) void gaussian_targets_kernel(const float* pose2d, const float* vis, float* out,
+                                                               int H, int W, float sigma) {
+  const int bk = blockIdx.x;
+  const float fx = pose2d[bk * 2 + 0], fy = pose2d[bk * 2 + 1];
+  const int x = (int)fx, y = (int)fy;                      // int(): truncation, as the reference
+  const bool on = (!vis || vis[bk] > 0.f) && x >= 0 && y >= 0 && x < W && y < H;
+  const int ulx = (int)rintf((float)x - 3.f * sigma - 1.f), uly = (int)rintf((float)y - 3.f * sigma - 1.f);
+  const int brx = (int)rintf((float)x + 3.f * sigma + 2.f), bry = (int)rintf((float)y + 3.f * sigma + 2.f);
+  // the reference's kernel image g has its peak at index 3*sigma+1 of a (6*sigma+3)-wide window placed at ul
+  const double c = 3.0 * (double)sigma + 1.0, inv = 1.0 / (2.0 * (double)sigma * (double)sigma);
+  float* o = out + (size_t)bk * H * W;
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    const int py = i / W, px = i % W;
+    float v = 0.f;
+    if (on && px >= ulx && px < brx && py >= uly && py < bry) {
+      const double dx = (double)(px - ulx) - c, dy = (double)(py - uly) - c;
+      v = (float)exp(-(dx * dx + dy * dy) * inv);
+    }
+    o[i] = v;
+  }
+}
+
+// ToTensor + Normalize of the reference's input pipeline (lib/dataset/transforms/build.py:84-85,
+// transforms.py:38-51): HWC u8 -> CHW f32, (v/255 - mean[c]) / std[c]
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* img, float* out, long long npix,
+                                                           long long hw, float m0, float m1, float m2, float s0,
+                                                           float s1, float s2) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / hw, r = p % hw;
+    const unsigned char* q = img + p * 3;
+    float* o = out + n * 3 * hw + r;
+    o[0] = ((float)q[0] / 255.f - m0) / s0;
+    o[hw] = ((float)q[1] / 255.f - m1) / s1;
+    o[2 * hw] = ((float)q[2] / 255.f - m2) / s2;
+  }
+}
+
 // per-map sum of (pred-gt)^2 or |pred-gt|
 __global__ __launch_bounds__(256) void hm_loss_map_kernel(const float* pred, const float* gt,
                                                           float* partial, int HW, int mode) {
@@ -258,6 +298,26 @@ extern "C" int hrnet_heatmap_loss_bwd(const float* pred, const float* gt, const 
   hipLaunchKernelGGL(hm_loss_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, pred, gt,
                      gout, dpred, n, 1.0f / (float)BK, mode);
   return hr_check_launch("heatmap_loss_bwd");
+}
+
+extern "C" int hrnet_gaussian_targets(const float* pose2d, const float* visibility, float* heatmaps, int BK, int H,
+                                      int W, float sigma, hr_stream_t stream) {
+  HR_REQUIRE(pose2d && heatmaps && BK > 0 && H > 0 && W > 0 && sigma > 0.f, "gaussian_targets: args");
+  hipLaunchKernelGGL(gaussian_targets_kernel, dim3(BK), dim3(256), 0, (hipStream_t)stream, pose2d, visibility,
+                     heatmaps, H, W, sigma);
+  return hr_check_launch("gaussian_targets");
+}
+
+extern "C" int hrnet_normalize_u8(const unsigned char* img_nhwc, float* out_nchw, int N, int H, int W,
+                                  const float* mean3, const float* std3, hr_stream_t stream) {
+  HR_REQUIRE(img_nhwc && out_nchw && mean3 && std3 && N > 0 && H > 0 && W > 0, "normalize_u8: args");
+  HR_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "normalize_u8: zero std");
+  const long long hw = (long long)H * W, npix = hw * N;
+  long long grid = (npix + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, img_nhwc, out_nchw,
+                     npix, hw, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return hr_check_launch("normalize_u8");
 }
 
 extern "C" int hrnet_spatial_softmax_fwd(const float* x, const float* temp, float* out, int BK, int HW,

@@ -70,6 +70,8 @@ _SIGS = {
     'hrnet_bn_bwd_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 6 + [_c_int, _c_vp],
     'hrnet_bilinear_cat': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 5 + [_c_vp],
     'hrnet_bilinear_cat_bwd': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 6 + [_c_vp],
+    'hrnet_gaussian_targets': [_c_vp] * 3 + [_c_int] * 3 + [_c_float, _c_vp],
+    'hrnet_normalize_u8': [_c_vp, _c_vp] + [_c_int] * 3 + [ctypes.POINTER(ctypes.c_float)] * 2 + [_c_vp],
     'hrnet_spatial_softmax_fwd': [_c_vp] * 3 + [_c_int] * 2 + [_c_vp],
     'hrnet_spatial_softmax_bwd': [_c_vp] * 6 + [_c_int] * 2 + [_c_vp],
     'hrnet_im2col_stem': [_c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],

@@ -278,6 +278,19 @@ int hrnet_decode_argmax(const float* hms, float* preds, float* maxvals, int BK, 
                         int inference_style, hr_stream_t stream);
 
 /*
+ * The data step either side of the path, on the device instead of the host loader:
+ *   hrnet_gaussian_targets: lib/dataset/target_generators/target_generators.py:14-53 - un-normalised
+ *     Gaussians, peak 1 at int(coord), window 6*sigma+3, zero map if invisible (visibility may be
+ *     NULL = all visible) or out of range. pose2d [BK,2] heat-map pixels (x,y), heatmaps [BK,H,W].
+ *   hrnet_normalize_u8: ToTensor + Normalize (lib/dataset/transforms/build.py:84-85): HWC u8 image
+ *     -> CHW f32 (v/255 - mean[c]) / std[c]; mean3/std3 are HOST arrays of 3 floats.
+ */
+int hrnet_gaussian_targets(const float* pose2d, const float* visibility, float* heatmaps, int BK, int H,
+                           int W, float sigma, hr_stream_t stream);
+int hrnet_normalize_u8(const unsigned char* img_nhwc, float* out_nchw, int N, int H, int W,
+                       const float* mean3, const float* std3, hr_stream_t stream);
+
+/*
  * Spatial softmax head of pose_hrnet_softmax (lib/models/pose_hrnet_softmax.py:520-524):
  * out[bk, :] = softmax(x[bk, :] * *temp) over the HW positions of each map, NCHW f32.
  * backward: dx = temp * out * (gout - sum(gout*out)); dtemp_partial[bk] = sum_i dz_i * x_i with

@@ -520,6 +520,32 @@ def test_spatial_softmax_with_temperature_forward_backward():
     assert abs(float(part.sum()) - float(temp.grad)) <= 1e-4 * max(1.0, abs(float(temp.grad)))
 
 
+def test_device_side_targets_and_normalisation_match_the_host_pipeline():
+    """Gaussian targets (reference target_generators.py:14-53, restated in hipnet/synth.py and
+    pinned there against the reference-shaped fixtures) and ToTensor+Normalize, as single launches."""
+    from dataset.target_generators import HeatmapGenerator, gaussian_targets, normalize_u8
+    from hipnet import synth
+    rng = np.random.default_rng(11)
+    pose = (rng.random((5, 21, 2)) * 80 - 8).astype(np.float32)          # some joints fall outside
+    pose[0, 0] = [0.2, 63.9]
+    pose[0, 1] = [63.99, 0.0]
+    vis = rng.random((5, 21, 1)) < 0.8
+    want = synth.gaussian_heatmaps(pose, vis, 64, 64, 2)
+    got = gaussian_targets(torch.from_numpy(pose).cuda(), torch.from_numpy(vis).cuda(), 64, 64, 2).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-7
+    assert np.array_equal(got == 0, want == 0)
+    gen = HeatmapGenerator(64, 21, sigma=2)
+    j = np.concatenate([pose[1], vis[1].astype(np.float32)], axis=1)
+    assert np.abs(gen(j).cpu().numpy() - want[1]).max() <= 1e-7
+    want_rect = synth.gaussian_heatmaps(pose[:2], vis[:2], 48, 40, 2)      # non-square maps
+    got_rect = gaussian_targets(torch.from_numpy(pose[:2]).cuda(), torch.from_numpy(vis[:2]).cuda(), 48, 40, 2)
+    assert np.abs(got_rect.cpu().numpy() - want_rect).max() <= 1e-7
+    u8 = torch.from_numpy(rng.integers(0, 256, (3, 32, 24, 3), dtype=np.uint8))
+    ref = (u8.float() / 255.0 - torch.tensor(synth.IMAGENET_MEAN)) / torch.tensor(synth.IMAGENET_STD)
+    out = normalize_u8(u8.cuda()).cpu()
+    assert float((out - ref.permute(0, 3, 1, 2)).abs().max()) <= 1e-6
+
+
 def test_adam_step_matches_torch():
     hh = _h()
     from hipnet import _capi as C
