@@ -52,7 +52,9 @@ def main():
     K = cfg.MODEL.NUM_JOINTS
     scale = cfg.MODEL.IMAGE_SIZE[0] / cfg.MODEL.HEATMAP_SIZE[0]
     thresholds = np.arange(1, 50)
-    err_sum, vis_sum, pck_hits = np.zeros(K), np.zeros(K), np.zeros((len(thresholds), K))
+    # accumulators and file formats of the reference (tools/evaluate_2D.py:166-169,270-294): per-joint error
+    # sums, PCK counted with a strict `<` over all visible joints, PCK2d.txt = two rows (thresholds, PCK)
+    err_sum, vis_sum, pck_hits = np.zeros(K), np.zeros(K), np.zeros(len(thresholds))
     timed, t_total = 0, 0.0
     with torch.no_grad():
         for i, ret in enumerate(loader):
@@ -71,15 +73,15 @@ def main():
             epe = np.linalg.norm(pred - gt, axis=2)
             err_sum += (epe * vis).sum(0)
             vis_sum += vis.sum(0)
-            pck_hits += ((epe[None] <= thresholds[:, None, None]) * vis[None]).sum(1)
+            pck_hits += ((epe[None] * vis[None] < thresholds[:, None, None]) * vis[None]).sum((1, 2))
     out_dir = os.path.join(cfg.OUTPUT_DIR or 'output', 'eval2D_results_' + cfg.EXP_NAME)
     os.makedirs(out_dir, exist_ok=True)
     mse_each = err_sum / np.maximum(vis_sum, 1)
-    pck = pck_hits / np.maximum(vis_sum, 1)[None]
+    pck = pck_hits / max(vis_sum.sum(), 1)
     np.savetxt(os.path.join(out_dir, 'mse2d_each_joint.txt'), mse_each, fmt='%.4f')
-    np.savetxt(os.path.join(out_dir, 'PCK2d.txt'), pck.mean(1), fmt='%.4f')
+    np.savetxt(os.path.join(out_dir, 'PCK2d.txt'), np.stack((thresholds, pck)))
     print('fps: {:.1f}'.format(timed / max(t_total, 1e-9)))
-    print('mean EPE {:.3f} px  PCK@20px {:.4f}  AUC(1-49px) {:.4f}'.format(mse_each.mean(), pck.mean(1)[19], pck.mean()))
+    print('mean EPE {:.3f} px  PCK@20px {:.4f}  AUC(1-49px) {:.4f}'.format(mse_each.mean(), pck[19], pck.mean()))
 
 
 if __name__ == '__main__':

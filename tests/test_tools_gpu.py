@@ -35,7 +35,12 @@ def test_train_then_evaluate_cli(tmp_path):
     ev = _run([sys.executable, 'tools/evaluate_2D.py', '--cfg', cfg, '--model_path', os.path.join(exp, 'final_state.pth.tar'),
                '--batch_size', '4', '--num_batches', '4', '--gpu', '0', 'OUTPUT_DIR', out], PKG)
     assert 'fps:' in ev and 'PCK@20px' in ev
-    assert os.path.exists(os.path.join(out, 'eval2D_results_RHD_HRNet_w32_max_hmloss_v1', 'PCK2d.txt'))
+    import numpy as np
+    res = os.path.join(out, 'eval2D_results_RHD_HRNet_w32_max_hmloss_v1')
+    pck = np.loadtxt(os.path.join(res, 'PCK2d.txt'))          # the reference's format: thresholds row, PCK row
+    mse = np.loadtxt(os.path.join(res, 'mse2d_each_joint.txt'))
+    assert pck.shape == (2, 49) and np.array_equal(pck[0], np.arange(1, 50)) and mse.shape == (21,)
+    assert np.all(np.diff(pck[1]) >= 0) and 0.0 <= pck[1, 0] and pck[1, -1] <= 1.0
 
 
 def test_train_cli_with_the_trainable_softmax_variant(tmp_path):
