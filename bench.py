@@ -69,8 +69,10 @@ def conv_flops_table(plan):
     for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
         for idx, op in enumerate(prog.ops):
             if op.kind == C.OP_CONV:
+                mode = C.call('hrnet_conv_mode', 1 if op.p[7] else 0, 1 if op.p[4] else 0, op.i[10], op.i[12],
+                              1 if op.p[6] else 0, 1 if op.p[2] else 0, op.i[11])
                 C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[4], op.i[7], op.i[8],
-                       op.i[9], op.i[10], 1 if op.p[7] else 0, buf, 160)
+                       op.i[9], op.i[10], mode, buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, False))
             elif op.kind == C.OP_WGRAD:
                 C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], buf, 160)
@@ -88,7 +90,7 @@ def traffic_of(kernel_name):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    m = re.match(r'(conv_bs|conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
+    m = re.match(r'(conv_bs|conv_fwd|conv_dg|conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
     if not m:
         return None
     key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])

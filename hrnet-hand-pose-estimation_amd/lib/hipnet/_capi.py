@@ -51,6 +51,7 @@ _SIGS = {
     'hrnet_event_destroy': [_c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
     'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
+    'hrnet_conv_mode': [_c_int] * 7,
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_kernel_name': [_c_int] * 10 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
@@ -93,7 +94,7 @@ _SIGS = {
 }
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
-          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_deform_conv_wgrad_blocks'}
+          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 
 _lib = None

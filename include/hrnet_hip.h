@@ -122,7 +122,12 @@ int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, floa
                           int Cout, int ks, int stride, int upz, int accumulate, hr_stream_t stream);
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,
-                           int bwdstats, char* buf, int buflen);
+                           int mode, char* buf, int buflen);
+/* the specialised kernel family a conv launch uses: 0 conv_kernel (everything by run-time flag), 1
+ * conv_bs_kernel (backward statistics), 2 conv_fwd_kernel (forward conv feeding a BatchNorm), 3
+ * conv_dg_kernel (plain input gradient) */
+int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumulate, int has_stats, int has_affine,
+                    int in_relu);
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
