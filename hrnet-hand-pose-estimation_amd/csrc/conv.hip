@@ -18,6 +18,10 @@ extern "C" int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int str
   return choose_tile(N, Ho, Wo, Cout, ks, stride).gx;   // one statistics row per workgroup
 }
 
+extern "C" int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks, int stride) {
+  return choose_tile(N, Ho, Wo, Cout, ks, stride, true).gx;
+}
+
 int hr_launch_conv(const HrOp& op, hipStream_t s) {
   const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cin = op.i[4], Ho = op.i[5],
             Wo = op.i[6], Cout = op.i[7], ks = op.i[8], upz = op.i[10];
@@ -61,7 +65,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
                "conv2d: output %dx%d does not match input %dx%d ks=%d stride=%d", Ho, Wo, H, W, ks, stride);
     a.Hz = H; a.Wz = W;
   }
-  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, op.i[9]);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, op.i[9], op.p[7] != nullptr);
   a.tiles_y = (Ho + tc.th - 1) / tc.th;
   a.tiles_x = (Wo + tc.tw - 1) / tc.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
@@ -124,7 +128,7 @@ extern "C" int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumula
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
 extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride,
                                       int upz, int mode, char* buf, int buflen) {
-  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS);
   static const int wp[5] = {4, 2, 2, 2, 2}, wc[5] = {1, 2, 2, 2, 2};
   const int kstride = (ks == 1 || upz) ? 1 : stride;
   const int km = conv_km(dtype, ks, Cin, tc.id);

@@ -548,13 +548,14 @@ struct TileChoice {
   int th, tw, bn, id, tpw, gx;
 };
 
-TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride) {
+TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool bs = false) {
   // id: 0 = 16x16/BN32 (4x1 waves), 1 = 8x16/BN64 (2x2), 2 = 8x8/BN64 (2x2), 3 = 8x8/BN32 (2x2),
   //     4 = 8x16/BN128 (2x2; 1x1 convs with many output channels: 64 FLOP per staged byte)
   TileChoice tc;
   if (stride == 2) tc = Cout >= 64 ? TileChoice{8, 8, 64, 2, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
   else if (Cout <= 32) tc = (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
-  else if (ks == 1 && Cout >= 128 && Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 128, 4, 1, 0};  // GEMM-like
+  // (not for backward-statistics launches: their epilogue operands do not fit 128 accumulators' registers)
+  else if (ks == 1 && Cout >= 128 && Wo >= 16 && Ho >= 16 && !bs) tc = TileChoice{8, 16, 128, 4, 1, 0};  // GEMM-like
   else if (Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 64, 1, 1, 0};
   else tc = TileChoice{8, 8, 64, 2, 1, 0};
   const int tiles = N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);

@@ -53,6 +53,7 @@ _SIGS = {
     'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
     'hrnet_conv_mode': [_c_int] * 7,
     'hrnet_conv_tiles': [_c_int] * 6,
+    'hrnet_conv_tiles_bwdstats': [_c_int] * 6,
     'hrnet_conv_kernel_name': [_c_int] * 10 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
@@ -93,7 +94,7 @@ _SIGS = {
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_reduce_blocks',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 

@@ -616,7 +616,7 @@ class Plan(object):
                             ptrs[7] = C.ptr(target.t)
                             ptrs[8] = C.ptr(x.t) if relu_out else None
                     if target is not None:
-                        nrows = C.call('hrnet_conv_tiles', x.N, x.H, x.W, x.C, ks, stride)
+                        nrows = C.call('hrnet_conv_tiles_bwdstats', x.N, x.H, x.W, x.C, ks, stride)
                         rows = self._f32(nrows * 2 * x.C)
                         ptrs[6] = C.ptr(rows)
                         target.bwd_rows = (rows, nrows)

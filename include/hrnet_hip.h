@@ -114,7 +114,7 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
  * (sum dz, sum dz*yraw) per channel with dz = v * [m > 0], m = bs_mask (or bs_y when bs_mask is
  * NULL) optionally mapped through bs_scale/bs_shift; no mask at all when bs_mask and bs_scale are
  * both NULL. bs_y / bs_mask are laid out like y. Rows are finished by hrnet_bn_bwd_finalize with
- * blocks = hrnet_conv_tiles(N,Ho,Wo,Cout,ks,stride).
+ * blocks = hrnet_conv_tiles_bwdstats(N,Ho,Wo,Cout,ks,stride).
  */
 int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, float* stats,
                           const void* bs_y, const void* bs_mask, const float* bs_scale,
@@ -131,6 +131,8 @@ int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumulate, int has
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
+/* rows of a hrnet_conv2d_bwdstats launch (its tile choice differs for wide 1x1 outputs) */
+int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks, int stride);
 
 /*
  * Weight gradient: slabs[s][Cout][ks*ks][Cin] f32 partial sums over disjoint pixel ranges

@@ -19,7 +19,7 @@ def case(N, H, Cc, ks):
     y = torch.zeros(N, H, H, Cc, device='cuda', dtype=dt)
     yr = torch.randn(N, H, H, Cc, device='cuda').to(dt); om = torch.randn(N, H, H, Cc, device='cuda').to(dt)
     sc = torch.rand(Cc, device='cuda') + 0.5; sh = torch.rand(Cc, device='cuda') - 0.5
-    tiles = C.call('hrnet_conv_tiles', N, H, H, Cc, ks, 1)
+    tiles = C.call('hrnet_conv_tiles_bwdstats', N, H, H, Cc, ks, 1)
     st = torch.zeros(tiles, 2, Cc, device='cuda')
     def plain(acc): C.call('hrnet_conv2d', 1, x.data_ptr(), wp.data_ptr(), None, None, None, y.data_ptr(), None, N, H, H, Cc, H, H, Cc, ks, 1, 0, 0, acc, C.stream_ptr())
     def bs(mode, acc): C.call('hrnet_conv2d_bwdstats', 1, x.data_ptr(), wp.data_ptr(), y.data_ptr(), st.data_ptr(), yr.data_ptr(), om.data_ptr() if mode == 2 else None,

@@ -309,7 +309,8 @@ def test_batchnorm_backward_through_upsampled_sum(dtype, sh):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('mode', ['bn_relu', 'bn_plain', 'sum_mask'])
-@pytest.mark.parametrize('case', [(2, 16, 16, 32, 32, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 8, 8, 256, 64, 1, 1)])
+@pytest.mark.parametrize('case', [(2, 16, 16, 32, 32, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 8, 8, 256, 64, 1, 1),
+                                  (2, 16, 16, 256, 64, 1, 1)])     # wide 1x1 output: its own tile choice
 def test_dgrad_epilogue_gathers_batchnorm_backward_sums(dtype, mode, case):
     """hrnet_conv2d_bwdstats: the input-gradient conv also leaves (sum dz, sum dz*y) rows of the
     BatchNorm behind its output; checked against the same sums taken from the stored gradient."""
@@ -330,7 +331,7 @@ def test_dgrad_epilogue_gathers_batchnorm_backward_sums(dtype, mode, case):
     dyd, yd, od = hh.nhwc(dy, dtype), hh.nhwc(yraw, dtype), hh.nhwc(outv, dtype)
     gx = hh.nhwc(prev, dtype)
     scd, sfd = sc.to(d), sf.to(d)
-    rows_n = C.call('hrnet_conv_tiles', N, H, W, Cin, ks, stride)
+    rows_n = C.call('hrnet_conv_tiles_bwdstats', N, H, W, Cin, ks, stride)
     rows = torch.full((rows_n, 2, Cin), float('nan'), device=d)
     C.call('hrnet_conv2d_bwdstats', hh.dt_id(dtype), dyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), rows.data_ptr(),
            yd.data_ptr(), od.data_ptr() if mode == 'sum_mask' else None,
