@@ -275,7 +275,6 @@ def main():
     from core.loss import HeatmapLoss
     from hipnet import synth
     from hipnet.optim import FlatAdam, GradSync
-    from oracle import hrnet_cpu as O    # cpu_baseline leg only
 
     yaml_name = 'RHD_HRNet_w32_max_hmloss_v1.yaml' if args.arch == 'w32' else 'RHD_HRNet_w48_softmax_hm-pose2dloss_v1.yaml'
     img_h, img_w = (256, 256) if args.arch == 'w32' else (384, 288)
@@ -353,6 +352,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline (oracle on host cores)')
+        from oracle import hrnet_cpu as O    # the cpu_baseline leg is the only user of oracle/ here
         cpu = cpu_baseline(sd, O.W32_EXTRA)
 
     if rank == 0:
