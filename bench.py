@@ -90,7 +90,7 @@ def traffic_of(kernel_name):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    m = re.match(r'(conv_bs|conv_fwd|conv_dg|conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
+    m = re.match(r'(conv_bs|conv_fwdb|conv_fwd|conv_dg|conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
     if not m:
         return None
     key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])

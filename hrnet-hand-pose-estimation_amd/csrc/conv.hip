@@ -9,6 +9,7 @@ namespace {
 inline int conv_mode(const ConvArgs& a, bool in_relu) {
   if (a.bs_y) return CONV_BS;
   if (!a.bias && !a.upz && !a.accumulate && a.stats) return CONV_FWD;
+  if (a.bias && !a.upz && !a.accumulate) return CONV_FWDB;
   if (!a.bias && !a.in_scale && !in_relu && !a.stats) return CONV_DG;
   return CONV_GENERIC;
 }
@@ -80,6 +81,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
     case CONV_BS: return hr_conv_launch_bs(l, s);
     case CONV_FWD: return hr_conv_launch_fwd(l, s);
     case CONV_DG: return hr_conv_launch_dg(l, s);
+    case CONV_FWDB: return hr_conv_launch_fwdb(l, s);
     default: return hr_conv_launch_generic(l, s);
   }
 }
@@ -132,7 +134,7 @@ extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin,
   static const int wp[5] = {4, 2, 2, 2, 2}, wc[5] = {1, 2, 2, 2, 2};
   const int kstride = (ks == 1 || upz) ? 1 : stride;
   const int km = conv_km(dtype, ks, Cin, tc.id);
-  static const char* names[4] = {"conv_kernel", "conv_bs_kernel", "conv_fwd_kernel", "conv_dg_kernel"};
-  return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", names[mode & 3],
+  static const char* names[5] = {"conv_kernel", "conv_bs_kernel", "conv_fwd_kernel", "conv_dg_kernel", "conv_fwdb_kernel"};
+  return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", names[mode >= 0 && mode < 5 ? mode : 0],
                   dtype == HR_F32 ? "float" : "__bf16", ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
 }

@@ -94,7 +94,8 @@ struct ConvCfg {
 //   CONV_FWD      forward conv feeding a BatchNorm: optional input affine/ReLU, statistics; no bias /
 //                 zero-stuffing / accumulate
 //   CONV_DG       plain input gradient: raw dY in, no bias, no statistics; zero-stuffing / accumulate by flag
-enum { CONV_GENERIC = 0, CONV_BS = 1, CONV_FWD = 2, CONV_DG = 3 };
+//   CONV_FWDB     CONV_FWD with a bias (the head convs)
+enum { CONV_GENERIC = 0, CONV_BS = 1, CONV_FWD = 2, CONV_DG = 3, CONV_FWDB = 4 };
 
 template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM, int MODE>
 __device__ __forceinline__ void conv_body(const ConvArgs& a) {
@@ -137,9 +138,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   // a backward-statistics launch is an input-gradient conv: raw dY in, no bias (checked by the launcher)
   const bool has_affine = RAW_IN ? false : a.in_scale != nullptr;
   const bool in_relu = RAW_IN ? false : a.in_relu != 0;
-  const bool A_UPZ = MODE == CONV_FWD ? false : a.upz != 0;
-  const bool A_ACC = MODE == CONV_FWD ? false : a.accumulate != 0;
-  const bool A_BIAS = MODE == CONV_GENERIC ? a.bias != nullptr : false;
+  constexpr bool FWDLIKE = MODE == CONV_FWD || MODE == CONV_FWDB;
+  const bool A_UPZ = FWDLIKE ? false : a.upz != 0;
+  const bool A_ACC = FWDLIKE ? false : a.accumulate != 0;
+  const bool A_BIAS = MODE == CONV_GENERIC ? a.bias != nullptr : MODE == CONV_FWDB;
 
   // per-lane LDS byte offsets of the MFMA operands
   int aoff[C::FC];
@@ -539,6 +541,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 }
 
 template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
+__global__ __launch_bounds__(256) void conv_fwdb_kernel(ConvArgs a) {
+  conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, CONV_FWDB>(a);
+}
+
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
 __global__ __launch_bounds__(256) void conv_dg_kernel(ConvArgs a) {
   conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, CONV_DG>(a);
 }
@@ -594,6 +601,7 @@ inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
     if constexpr (MODE == CONV_BS) hipLaunchKernelGGL((conv_bs_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);        \
     else if constexpr (MODE == CONV_FWD) hipLaunchKernelGGL((conv_fwd_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a); \
     else if constexpr (MODE == CONV_DG) hipLaunchKernelGGL((conv_dg_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);   \
+    else if constexpr (MODE == CONV_FWDB) hipLaunchKernelGGL((conv_fwdb_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a); \
     else hipLaunchKernelGGL((conv_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);                    \
   } while (0)
 
@@ -654,6 +662,7 @@ int hr_conv_launch_generic(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_bs(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_fwd(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_dg(const ConvLaunch& l, hipStream_t s);
+int hr_conv_launch_fwdb(const ConvLaunch& l, hipStream_t s);
 
 #define HR_DEFINE_CONV_LAUNCH(NAME, MODE)                                              \
   int NAME(const ConvLaunch& l, hipStream_t s) {                                       \

@@ -125,7 +125,7 @@ int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, 
                            int mode, char* buf, int buflen);
 /* the specialised kernel family a conv launch uses: 0 conv_kernel (everything by run-time flag), 1
  * conv_bs_kernel (backward statistics), 2 conv_fwd_kernel (forward conv feeding a BatchNorm), 3
- * conv_dg_kernel (plain input gradient) */
+ * conv_dg_kernel (plain input gradient), 4 conv_fwdb_kernel (forward conv with bias) */
 int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumulate, int has_stats, int has_affine,
                     int in_relu);
 int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);

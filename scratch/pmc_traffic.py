@@ -6,7 +6,7 @@ import csv, glob, collections, json, re, sys
 def canon(name):
     """canonical key 'conv|3|1|8|8|32|2|2|2' from rocprofv3's (sometimes mis-demangled) kernel names"""
     kind = ('conv' if 'conv_kernel' in name else 'conv_bs' if 'conv_bs_kernel' in name else
-            'conv_fwd' if 'conv_fwd_kernel' in name else 'conv_dg' if 'conv_dg_kernel' in name else
+            'conv_fwd' if 'conv_fwd_kernel' in name else 'conv_fwdb' if 'conv_fwdb_kernel' in name else 'conv_dg' if 'conv_dg_kernel' in name else
             'wgrad' if 'wgrad_kernel' in name else None)
     if kind is None:
         m = re.search(r'(\w+_kernel)', name)
