@@ -75,7 +75,7 @@ def conv_flops_table(plan):
                        op.i[9], op.i[10], mode, buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, False))
             elif op.kind == C.OP_WGRAD:
-                C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], buf, 160)
+                C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[4], op.i[8], op.i[9], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, True))
     return out
 

@@ -14,6 +14,9 @@
 // reproducible, no float atomics).
 #include <stdio.h>
 
+#include <type_traits>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -229,8 +232,11 @@ struct WgCfg {
   int th, tw, bco, kc, id;
 };
 
-WgCfg choose_wg(int dtype, int Ho, int Wo, int Cout, int ks, int stride) {
+WgCfg choose_wg(int dtype, int Ho, int Wo, int Cout, int ks, int stride, int Cin = 0) {
   const bool f32 = dtype == HR_F32;
+  // the GEMM-shaped head layer (480x480, 720x720): 128x128 output tiles halve the operand traffic per FLOP
+  // (measured 508 -> 365 us); narrower layers lose with it (64->256: 34 -> 48 us)
+  if (ks == 1 && !f32 && Cout >= 256 && Cin >= 256) return WgCfg{8, 16, 128, 128, 11};
   if (ks == 1) return f32 ? WgCfg{8, 16, 64, 32, 10} : WgCfg{8, 16, 64, 64, 10};
   const bool big = Ho >= 16 && Wo >= 16 && stride == 1;
   const int kc = f32 ? 16 : 32;
@@ -242,7 +248,9 @@ template <typename T, int KC3, int KC1>
 int launch_wg(const WgradArgs& a, const WgCfg& c, int ks, int stride, dim3 grid, hipStream_t s) {
 #define WG(KS_, ST_, TH_, TW_, BCO_, KC_, WCO_, WN_) \
   hipLaunchKernelGGL((wgrad_kernel<T, KS_, ST_, TH_, TW_, BCO_, KC_, WCO_, WN_>), grid, dim3(256), 0, s, a)
-  if (ks == 1) {
+  if (ks == 1 && c.id == 11) {
+    if constexpr (std::is_same<T, bf16_t>::value) WG(1, 1, 8, 16, 128, 128, 2, 2);
+  } else if (ks == 1) {
     WG(1, 1, 8, 16, 64, KC1, 2, 2);
   } else if (stride == 1) {
     switch (c.id) {
@@ -263,7 +271,7 @@ int launch_wg(const WgradArgs& a, const WgCfg& c, int ks, int stride, dim3 grid,
 
 extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks,
                                   int stride) {
-  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);
   const int tiles = N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
   const int gy = (Cout + c.bco - 1) / c.bco;
   const int gz = (Cin + c.kc - 1) / c.kc;
@@ -303,7 +311,7 @@ int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   const int pad = ks / 2;
   HR_REQUIRE((H + 2 * pad - ks) / stride + 1 == Ho && (W + 2 * pad - ks) / stride + 1 == Wo,
              "wgrad: shape mismatch");
-  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);
   WgradArgs a;
   a.x = (const char*)op.p[0];
   a.dy = (const char*)op.p[1];
@@ -333,9 +341,9 @@ extern "C" int hrnet_conv2d_wgrad(int dtype, const void* x, const void* dy, cons
   return hr_launch_wgrad(op, (hipStream_t)stream);
 }
 
-extern "C" int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf,
+extern "C" int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int Cin, int ks, int stride, char* buf,
                                        int buflen) {
-  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride);
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);
   int wco = 2, wn = 2;
   if (ks == 3 && c.bco == 32) { wco = 1; wn = 4; }
   return snprintf(buf, buflen, "wgrad_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", dtype == HR_F32 ? "float" : "__bf16",

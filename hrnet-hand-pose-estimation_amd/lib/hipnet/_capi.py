@@ -55,7 +55,7 @@ _SIGS = {
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_tiles_bwdstats': [_c_int] * 6,
     'hrnet_conv_kernel_name': [_c_int] * 10 + [ctypes.c_char_p, _c_int],
-    'hrnet_wgrad_kernel_name': [_c_int] * 6 + [ctypes.c_char_p, _c_int],
+    'hrnet_wgrad_kernel_name': [_c_int] * 7 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
     'hrnet_wgrad_splits': [_c_int] * 8,
     'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],

@@ -128,7 +128,8 @@ int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, 
  * conv_dg_kernel (plain input gradient), 4 conv_fwdb_kernel (forward conv with bias) */
 int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumulate, int has_stats, int has_affine,
                     int in_relu);
-int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int ks, int stride, char* buf, int buflen);
+int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int Cin, int ks, int stride, char* buf,
+                            int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
 /* rows of a hrnet_conv2d_bwdstats launch (its tile choice differs for wide 1x1 outputs) */
