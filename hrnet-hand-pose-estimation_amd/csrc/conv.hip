@@ -20,7 +20,7 @@ extern "C" int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int str
 }
 
 extern "C" int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks, int stride) {
-  return choose_tile(N, Ho, Wo, Cout, ks, stride, true).gx;
+  return choose_tile(N, Ho, Wo, Cout, ks, stride, true, ks == 3 && stride == 2).gx;
 }
 
 int hr_launch_conv(const HrOp& op, hipStream_t s) {
@@ -55,18 +55,23 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.N = N; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.in_relu = op.i[11]; a.upz = upz; a.accumulate = op.i[12];
+  const int mode = conv_mode(a, op.i[11] != 0);
+  // input gradient of a 3x3 stride-2 conv: the input-gradient bodies evaluate the four output parities
+  // from the real dY tile (S2D, template stride 4); other modes read it as a zero-stuffed grid
+  const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
   if (upz) {
     HR_REQUIRE(ks == 3, "conv2d: upz needs a 3x3 kernel");
     HR_REQUIRE((Ho + 1) / 2 == H && (Wo + 1) / 2 == W, "conv2d: upz shape mismatch");
-    stride = 1;
-    a.Hz = Ho; a.Wz = Wo;
+    stride = s2d ? 4 : 1;
+    if (s2d) { a.upz = 0; a.Hz = H; a.Wz = W; }
+    else { a.Hz = Ho; a.Wz = Wo; }
   } else {
     const int pad = ks / 2;
     HR_REQUIRE((H + 2 * pad - ks) / stride + 1 == Ho && (W + 2 * pad - ks) / stride + 1 == Wo,
                "conv2d: output %dx%d does not match input %dx%d ks=%d stride=%d", Ho, Wo, H, W, ks, stride);
     a.Hz = H; a.Wz = W;
   }
-  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, op.i[9], op.p[7] != nullptr);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, op.i[9], op.p[7] != nullptr, s2d);
   a.tiles_y = (Ho + tc.th - 1) / tc.th;
   a.tiles_x = (Wo + tc.tw - 1) / tc.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
@@ -77,7 +82,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   // runs the stride-1 kernel with that tile
   ConvLaunch l;
   l.a = a; l.tc = tc; l.dtype = dtype; l.N = N; l.ks = ks; l.stride = stride;
-  switch (conv_mode(a, op.i[11] != 0)) {
+  switch (mode) {
     case CONV_BS: return hr_conv_launch_bs(l, s);
     case CONV_FWD: return hr_conv_launch_fwd(l, s);
     case CONV_DG: return hr_conv_launch_dg(l, s);
@@ -130,9 +135,10 @@ extern "C" int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumula
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
 extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride,
                                       int upz, int mode, char* buf, int buflen) {
-  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS);
-  static const int wp[5] = {4, 2, 2, 2, 2}, wc[5] = {1, 2, 2, 2, 2};
-  const int kstride = (ks == 1 || upz) ? 1 : stride;
+  const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS, s2d);
+  static const int wp[8] = {4, 2, 2, 2, 2, 0, 4, 2}, wc[8] = {1, 2, 2, 2, 2, 0, 1, 2};
+  const int kstride = s2d ? 4 : (ks == 1 || upz) ? 1 : stride;
   const int km = conv_km(dtype, ks, Cin, tc.id);
   static const char* names[5] = {"conv_kernel", "conv_bs_kernel", "conv_fwd_kernel", "conv_dg_kernel", "conv_fwdb_kernel"};
   return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", names[mode >= 0 && mode < 5 ? mode : 0],

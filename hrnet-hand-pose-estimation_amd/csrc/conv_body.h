@@ -57,8 +57,11 @@ struct ConvCfg {
   static constexpr int KC = KSTEP * KM;            // channels staged per chunk (KM fragment steps)
   static constexpr int VPP = KC / VEC;             // 16-byte vectors per pixel per chunk
   static constexpr int TAPS = KS * KS;
-  static constexpr int HALO_H = (TH - 1) * STRIDE + KS;
-  static constexpr int HALO_W = (TW - 1) * STRIDE + KS;
+  // STRIDE == 4 is the four-parity input gradient of a 3x3 stride-2 conv (S2D, see conv_body): the staged
+  // image is the (TH/2+1) x (TW/2+1) dY tile that the TH x TW output tile depends on
+  static constexpr bool S2D = STRIDE == 4;
+  static constexpr int HALO_H = S2D ? TH / 2 + 1 : (TH - 1) * STRIDE + KS;
+  static constexpr int HALO_W = S2D ? TW / 2 + 1 : (TW - 1) * STRIDE + KS;
   static constexpr int PIXB = KC * (int)sizeof(T) + 16;          // padded pixel stride (bytes)
   static constexpr int WROWB = TAPS * KC * (int)sizeof(T) + 16;  // padded weight-row stride
   static constexpr int XBYTES = HALO_H * HALO_W * PIXB;
@@ -79,6 +82,7 @@ struct ConvCfg {
   static_assert(PM % 16 == 0 && CN % 16 == 0, "fragment multiples");
   static_assert(256 % VPP == 0, "each thread keeps one channel vector");
   static_assert(XV <= 31, "validity mask");
+  static_assert(!S2D || (KS == 3 && FP == 4 && (TH / 2) * (TW / 2) == WP * 16), "S2D: one fragment per parity");
 };
 
 // A workgroup walks `tpw` pixel tiles x `nch` K-chunks as a flat sequence of stages. The global
@@ -127,7 +131,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   }
   if (wg_p >= a.gx) return;
   const int n0 = wg_nb * BN;
-  constexpr int PAD = KS / 2;
+  constexpr bool S2D = C::S2D;
+  constexpr int PAD = S2D ? 0 : KS / 2;
+  constexpr int SST = S2D ? 1 : STRIDE;     // stride of the staged image
+  constexpr int TIH = S2D ? TH / 2 : TH, TIW = S2D ? TW / 2 : TW;   // tile extent in staged-image steps
 
   const int nch = (a.Cin + C::KC - 1) / C::KC;
   const int tile0 = wg_p * a.tpw;
@@ -156,10 +163,28 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   int boff[C::FP];
 #pragma unroll
   for (int fp = 0; fp < C::FP; ++fp) {
-    const int p = wp * C::PM + fp * 16 + li;
-    const int py = p / TW, px = p % TW;
-    boff[fp] = ((py * STRIDE) * C::HALO_W + px * STRIDE) * C::PIXB + lg * 16;
+    if constexpr (S2D) {
+      // fragment fp = output parity; lane li of wave wp = dY position q of the tile (same for every parity)
+      const int q = wp * 16 + li;
+      boff[fp] = ((q / TIW) * C::HALO_W + q % TIW) * C::PIXB + lg * 16;
+    } else {
+      const int p = wp * C::PM + fp * 16 + li;
+      const int py = p / TW, px = p % TW;
+      boff[fp] = ((py * STRIDE) * C::HALO_W + px * STRIDE) * C::PIXB + lg * 16;
+    }
   }
+  // output pixel of (fragment, lane) within the tile
+  auto out_yx = [&](int fp, int& y, int& x) {
+    if constexpr (S2D) {
+      const int q = wp * 16 + li;
+      y = 2 * (q / TIW) + (fp >> 1);
+      x = 2 * (q % TIW) + (fp & 1);
+    } else {
+      const int p = wp * C::PM + fp * 16 + li;
+      y = p / TW;
+      x = p % TW;
+    }
+  };
 
   // staging registers of the stage in flight
   V16 xr[C::XV], wr[C::WV];
@@ -207,7 +232,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int t = s / nch, ch = s - t * nch;
     const int n = __builtin_amdgcn_readfirstlane(cur_n), ty = __builtin_amdgcn_readfirstlane(cur_ty),
               tx = __builtin_amdgcn_readfirstlane(cur_tx);
-    const int iy0 = ty * TH * STRIDE - PAD, ix0 = tx * TW * STRIDE - PAD;
+    const int iy0 = ty * TIH * SST - PAD, ix0 = tx * TIW * SST - PAD;
     const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
     if (has_affine && cvalid) {
@@ -345,8 +370,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
               tx = __builtin_amdgcn_readfirstlane(ep_tx);
 #pragma unroll
     for (int fp = 0; fp < C::FP; ++fp) {
-      const int p = wp * C::PM + fp * 16 + li;
-      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      int oy, ox;
+      out_yx(fp, oy, ox);
+      oy += ty * TH; ox += tx * TW;
       if (cok && oy < a.Ho && ox < a.Wo) {
         const size_t off = ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase) * sizeof(T);
         lane_load(a.bs_y + off, pre_y[fp]);
@@ -390,22 +416,44 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 #ifndef HR_BS_LATE
       if constexpr (BS) { if (ch + 1 == nch) bs_prefetch(); }
 #endif
+      if constexpr (S2D) {
+        // dx[2y+py][2x+px] = sum over the taps of the flipped kernel whose zero-stuffed source is a real dY
+        // element: tap index 1 <-> parity 0 (dY[y]); 0 <-> parity 1 (dY[y]); 2 <-> parity 1 (dY[y+1]).
+        // 9 tap-steps feed the 4 parity fragments (1 + 2 + 2 + 4): a quarter of the zero-stuffed MFMAs.
 #pragma unroll
-      for (int tp = 0; tp < C::TAPS; ++tp) {
-        const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
+        for (int tp = 0; tp < 9; ++tp) {
+          constexpr int KB = C::KSTEP * (int)sizeof(T);
+          const int tr = tp / 3, ts = tp % 3;
+          const int fpq = ((tr != 1) ? 2 : 0) + ((ts != 1) ? 1 : 0);
+          const int tapb = ((tr == 2 ? 1 : 0) * C::HALO_W + (ts == 2 ? 1 : 0)) * C::PIXB;
 #pragma unroll
-        for (int kk = 0; kk < KM; ++kk) {
-          constexpr int KB = C::KSTEP * (int)sizeof(T);   // bytes of one fragment step
-          V16 af[C::FC], bf[C::FP];
+          for (int kk = 0; kk < KM; ++kk) {
+            const V16 bfv = *(const V16*)(xl + boff[0] + tapb + kk * KB);
 #pragma unroll
-          for (int fc = 0; fc < C::FC; ++fc)
-            af[fc] = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
+            for (int fc = 0; fc < C::FC; ++fc) {
+              const V16 afv = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
+              acc[fc][fpq] = mma16<T>(afv, bfv, acc[fc][fpq]);
+            }
+          }
+        }
+      } else {
 #pragma unroll
-          for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb + kk * KB);
-#pragma unroll
-          for (int fc = 0; fc < C::FC; ++fc)
-#pragma unroll
-            for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
+        for (int tp = 0; tp < C::TAPS; ++tp) {
+          const int tapb = ((tp / KS) * C::HALO_W + (tp % KS)) * C::PIXB;
+  #pragma unroll
+          for (int kk = 0; kk < KM; ++kk) {
+            constexpr int KB = C::KSTEP * (int)sizeof(T);   // bytes of one fragment step
+            V16 af[C::FC], bf[C::FP];
+  #pragma unroll
+            for (int fc = 0; fc < C::FC; ++fc)
+              af[fc] = *(const V16*)(wl + aoff[fc] + tp * C::KC * (int)sizeof(T) + kk * KB);
+  #pragma unroll
+            for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xl + boff[fp] + tapb + kk * KB);
+  #pragma unroll
+            for (int fc = 0; fc < C::FC; ++fc)
+  #pragma unroll
+              for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<T>(af[fc], bf[fp], acc[fc][fp]);
+          }
         }
       }
       STAMP();
@@ -421,8 +469,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     advance(ep_n, ep_ty, ep_tx);
 #pragma unroll
     for (int fp = 0; fp < C::FP; ++fp) {
-      const int p = wp * C::PM + fp * 16 + li;
-      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      int oy, ox;
+      out_yx(fp, oy, ox);
+      oy += ty * TH; ox += tx * TW;
       const bool pok = cok && oy < a.Ho && ox < a.Wo;
       float vals[C::LANE_C];
 #pragma unroll
@@ -555,11 +604,13 @@ struct TileChoice {
   int th, tw, bn, id, tpw, gx;
 };
 
-TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool bs = false) {
+TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool bs = false, bool s2d = false) {
   // id: 0 = 16x16/BN32 (4x1 waves), 1 = 8x16/BN64 (2x2), 2 = 8x8/BN64 (2x2), 3 = 8x8/BN32 (2x2),
   //     4 = 8x16/BN128 (2x2; 1x1 convs with many output channels: 64 FLOP per staged byte)
+  //     6 = 16x16/BN32 (4x1), 7 = 8x16/BN64 (2x2): four-parity input gradient of a stride-2 conv (S2D)
   TileChoice tc;
-  if (stride == 2) tc = Cout >= 64 ? TileChoice{8, 8, 64, 2, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
+  if (s2d) tc = Cout >= 64 ? TileChoice{8, 16, 64, 7, 1, 0} : TileChoice{16, 16, 32, 6, 1, 0};
+  else if (stride == 2) tc = Cout >= 64 ? TileChoice{8, 8, 64, 2, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
   else if (Cout <= 32) tc = (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
   // (not for backward-statistics launches: their epilogue operands do not fit 128 accumulators' registers)
   else if (ks == 1 && Cout >= 128 && Wo >= 16 && Ho >= 16 && !bs) tc = TileChoice{8, 16, 128, 4, 1, 0};  // GEMM-like
@@ -593,7 +644,7 @@ TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool
 inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
   const int kstep = dtype == HR_F32 ? 16 : 32;
   if (ks == 1) return Cin <= 2 * kstep ? 2 : 4;
-  return tile_id == 3 ? 2 : 1;
+  return tile_id == 3 ? 2 : 1;   // (S2D tiles 6, 7: 1)
 }
 
 #define LAUNCH_CONV(...)                                                                              \
@@ -609,6 +660,11 @@ template <int MODE, typename T, int KS, int STRIDE, int KM>
 int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
   const int gy_ = (a.Cout + tc.bn - 1) / tc.bn;
   dim3 grid((unsigned)(gy_ == 1 ? tc.gx : (tc.gx + 7) / 8 * 8 * gy_));
+  if constexpr (STRIDE == 4) {
+    if (tc.id == 6) LAUNCH_CONV(T, 3, 4, 16, 16, 32, 4, 1, 1);
+    else LAUNCH_CONV(T, 3, 4, 8, 16, 64, 2, 2, 1);
+    return hr_check_launch("conv2d");
+  } else
   switch (tc.id) {
     case 0:   // (stride-2 convs only use the 8x8 tiles: their halo is (2*T+1)^2)
       if constexpr (STRIDE == 1)
@@ -635,6 +691,9 @@ int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
 template <int MODE, typename T, int KS, int STRIDE>
 int launch_cfg(const ConvArgs& a, const TileChoice& tc, int N, hipStream_t s) {
   const int km = conv_km(TT<T>::ID, KS, a.Cin, tc.id);
+  if constexpr (STRIDE == 4) {
+    return launch_km<MODE, T, 3, 4, 1>(a, tc, s);
+  } else
   if constexpr (KS == 1) {
     return km == 2 ? launch_km<MODE, T, 1, 1, 2>(a, tc, s) : launch_km<MODE, T, 1, 1, 4>(a, tc, s);
   } else {
@@ -644,6 +703,10 @@ int launch_cfg(const ConvArgs& a, const TileChoice& tc, int N, hipStream_t s) {
 
 template <int MODE, typename T>
 int launch_t(const ConvArgs& a, const TileChoice& tc, int N, int ks, int stride, hipStream_t s) {
+  if (stride == 4) {   // four-parity stride-2 input gradient: only the input-gradient bodies carry it
+    if constexpr (MODE == CONV_BS || MODE == CONV_DG) return launch_cfg<MODE, T, 3, 4>(a, tc, N, s);
+    else return HR_E_BADARG;
+  }
   if (ks == 1) return launch_cfg<MODE, T, 1, 1>(a, tc, N, s);
   if (stride == 1) return launch_cfg<MODE, T, 3, 1>(a, tc, N, s);
   return launch_cfg<MODE, T, 3, 2>(a, tc, N, s);
