@@ -413,9 +413,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
       __syncthreads();
       STAMP();
       if (s + 1 < nstage) load_stage(s + 1);  // in flight while the MFMAs below run
-#ifndef HR_BS_LATE
       if constexpr (BS) { if (ch + 1 == nch) bs_prefetch(); }
-#endif
       if constexpr (S2D) {
         // dx[2y+py][2x+px] = sum over the taps of the flipped kernel whose zero-stuffed source is a real dY
         // element: tap index 1 <-> parity 0 (dY[y]); 0 <-> parity 1 (dY[y]); 2 <-> parity 1 (dY[y+1]).
@@ -511,9 +509,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
           }
         }
         if constexpr (BS) {
-#ifdef HR_BS_LATE
-          if (fp == 0) bs_prefetch();
-#endif
           // vals now hold the finished gradient of this output element
           float yv[C::LANE_C], mv[C::LANE_C];
           lane_unpack(pre_y[fp], yv);

@@ -14,6 +14,18 @@ Dataflow conventions
   Grad  every Act has a gradient buffer. For a raw+BN act it first accumulates the gradient
         w.r.t. the post-activation value, then BatchNorm backward rewrites it in place into the
         gradient w.r.t. the raw conv output (two-stage deterministic reductions).
+
+Scheduling
+  Lanes  ops carry a lane (HIP stream); EVENT_RECORD / STREAM_WAIT ops order them. The branches of a
+         HighResolutionModule run on their own lanes, and the fuse-layer convs stay on the lane of the
+         branch they read; only the sums wait for all lanes (HRNET_LANES=0: one stream).
+  Fused BatchNorm-backward sums  the input-gradient conv that writes the LAST contribution to an
+         activation gradient gathers (sum dz, sum dz*y) in its epilogue (hrnet_conv2d_bwdstats), which
+         replaces the separate reduction pass for ~80 % of the BatchNorms (HRNET_FUSE_BWDSTATS=0: off).
+  Batched slab sums  every layer keeps its own weight-gradient slab region; one table-driven launch per
+         lane segment sums them (HRNET_BATCH_WRED=0: per-layer launches on shared scratch).
+  Bucket marks  op indices at which every gradient above a flat offset is final (module boundaries and
+         every ~16 MB on lane 0): hipnet.optim.GradSync issues its all-reduces there.
 """
 import ctypes
 import os
