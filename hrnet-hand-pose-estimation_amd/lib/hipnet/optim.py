@@ -65,7 +65,7 @@ class GradSync(object):
     Installed as `model._segment_hook`; engine.Plan._run_segments calls `after(op_index)` right
     after enqueueing a backward segment."""
 
-    def __init__(self, model, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, model, bucket_bytes=16 << 20, process_group=None):
         import torch.distributed as dist
         self.dist = dist
         self.pg = process_group
