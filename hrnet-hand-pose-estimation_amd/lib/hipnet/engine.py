@@ -412,14 +412,27 @@ class Plan(object):
         if side and fuse_lanes:
             self.fwd.join(side)
             self._tape(('join', side))
+        # the sums of the module outputs run on the lane of their output branch (a second fork/join): in the
+        # backward pass that spreads a module's 16 sum-term passes over the lanes, and every consumer of a
+        # branch gradient sits on that branch's lane
+        sum_lanes = side and fuse_lanes and os.environ.get('HRNET_SUM_LANES', '1') != '0'
+        if sum_lanes:
+            self.fwd.fork(side)
+            self._tape(('fork', side))
         outs = []
         for i in range(nb):
+            if sum_lanes:
+                self.fwd.lane = i if i in side else 0
             terms = [term_of[(i, j)][0] for j in range(nb)]
             shifts = [term_of[(i, j)][1] for j in range(nb)]
             # the output-resolution term first (sum_terms sizes the output from term 0)
             order = sorted(range(nb), key=lambda q: shifts[q])
             outs.append(self.sum([terms[q] for q in order], [shifts[q] for q in order], True,
                                  '{}.fuse.{}'.format(pre, i)))
+        self.fwd.lane = 0
+        if sum_lanes:
+            self.fwd.join(side)
+            self._tape(('join', side))
         return outs
 
     # ---- backward recording ---------------------------------------------------------------
