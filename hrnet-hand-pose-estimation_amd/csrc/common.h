@@ -107,59 +107,6 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
-// Stage the input halo tile [HALO_H][HALO_W][KC channels from c0] of image n into LDS (pixel
-// stride PIXB bytes). The producer's BatchNorm affine (+ReLU) is applied on the way; padding
-// and the zero-stuffed grid of a stride-2 input gradient (upz) are zero AFTER the transform.
-template <typename T, int KC, int HALO_H, int HALO_W, int PIXB>
-__device__ __forceinline__ void stage_halo(char* xl, const char* x, int n, int H, int W, int Cin,
-                                           int Hz, int Wz, int iy0, int ix0, int c0,
-                                           const float* in_scale, const float* in_shift,
-                                           int in_relu, int upz, int tid) {
-  constexpr int VEC = TT<T>::VEC;
-  constexpr int VPP = KC / VEC;  // 16-byte vectors per pixel
-  static_assert(256 % VPP == 0, "each thread keeps one channel vector");
-  const int v = tid % VPP;
-  const int c = c0 + v * VEC;
-  const bool cvalid = c < Cin;
-  const bool has_affine = in_scale != nullptr;
-  float sc[VEC], sh[VEC];
-  if (has_affine && cvalid) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      sc[j] = in_scale[c + j];
-      sh[j] = in_shift[c + j];
-    }
-  }
-  for (int idx = tid; idx < HALO_H * HALO_W * VPP; idx += 256) {
-    const int pix = idx / VPP;
-    const int hy = pix / HALO_W, hx = pix % HALO_W;
-    const int gy = iy0 + hy, gx = ix0 + hx;
-    bool ok = cvalid && gy >= 0 && gy < Hz && gx >= 0 && gx < Wz;
-    int sy = gy, sx = gx;
-    if (upz) {
-      ok = ok && !((gy | gx) & 1);
-      sy = gy >> 1;
-      sx = gx >> 1;
-      ok = ok && sy < H && sx < W;
-    }
-    V16 val = v16_zero();
-    if (ok) {
-      val = *(const V16*)(x + ((size_t)((n * H + sy) * W + sx) * Cin + c) * sizeof(T));
-      if (has_affine || in_relu) {
-        float f[VEC];
-        v16_unpack<T>(val, f);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (in_relu) f[j] = fmaxf(f[j], 0.f);
-        }
-        val = v16_pack<T>(f);
-      }
-    }
-    *(V16*)(xl + pix * PIXB + v * 16) = val;
-  }
-}
-
 // host-side error plumbing (api.hip)
 void hr_set_error(const char* fmt, ...);
 int hr_check_launch(const char* what);
