@@ -33,7 +33,10 @@ for p in (REPO, os.path.join(PKG, 'lib')):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-GFLOP_PER_IMG = {'w32': 67.70, 'w48': 236.5}      # fwd+bwd conv FLOPs / image, BASELINE.md section 2
+GFLOP_PER_IMG = {'w32': 67.70, 'w48': 236.5}
+# layer-wise roofline of SURVEY 8d: sum over the conv layers of max(FLOP / MFMA peak, conv in+out bytes / 8 TB/s) for
+# bf16, forward 16.4 us per w32 image; the training step is taken as 3x that (dgrad and wgrad move the same tensors)
+LAYERWISE_US_PER_IMG = {('w32', 'bf16'): 3 * 16.4}      # fwd+bwd conv FLOPs / image, BASELINE.md section 2
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
 
 
@@ -369,6 +372,8 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': 'dp{}'.format(world)},
             'step_mfma_frac': round(value * GFLOP_PER_IMG[args.arch] / 1e3 / (world * PEAK_TFLOPS[args.dtype]), 5),
             'final_loss': final_loss,
+            'layerwise_roofline_frac': (round(value * LAYERWISE_US_PER_IMG[(args.arch, args.dtype)] * 1e-6 / world, 5)
+                                        if (args.arch, args.dtype) in LAYERWISE_US_PER_IMG else None),
             'roofline': roof, 'cpu_baseline': cpu,
         }
         out.update(extra_out)
