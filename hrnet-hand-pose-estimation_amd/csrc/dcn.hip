@@ -68,19 +68,32 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int oc0, int oc
     const int c = a.c0 + cl;
     const float* plane = a.in + ((size_t)b * a.C + c) * a.H * a.W;
     const float* offp = a.off + ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + (size_t)y * a.Wo + x;
-    for (int k = 0; k < K; ++k) {
-      const int i = k / a.kw, j = k % a.kw;
-      const float h = (float)(y * a.sh - a.ph + i * a.dh) + offp[(size_t)(2 * k) * plane_o];
-      const float w = (float)(x * a.sw - a.pw + j * a.dw) + offp[(size_t)(2 * k + 1) * plane_o];
-      const float val = dcn_inside(h, w, a.H, a.W) ? dcn_sample(plane, a.H, a.W, h, w) : 0.f;
-      const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OC);
+    // three taps at a time: their 6 offset loads, then their 12 gathers, are in flight together
+    for (int k0 = 0; k0 < K; k0 += 3) {
+      float hh[3], ww[3], vv[3];
 #pragma unroll
-      for (int o = 0; o < OC / 4; ++o) {
-        const float4 w4 = wk[o];
-        acc[4 * o] = fmaf(w4.x, val, acc[4 * o]);
-        acc[4 * o + 1] = fmaf(w4.y, val, acc[4 * o + 1]);
-        acc[4 * o + 2] = fmaf(w4.z, val, acc[4 * o + 2]);
-        acc[4 * o + 3] = fmaf(w4.w, val, acc[4 * o + 3]);
+      for (int u = 0; u < 3; ++u) {
+        const int k = k0 + u < K ? k0 + u : K - 1;
+        const int i = k / a.kw, j = k % a.kw;
+        hh[u] = (float)(y * a.sh - a.ph + i * a.dh) + offp[(size_t)(2 * k) * plane_o];
+        ww[u] = (float)(x * a.sw - a.pw + j * a.dw) + offp[(size_t)(2 * k + 1) * plane_o];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        vv[u] = (k0 + u < K && dcn_inside(hh[u], ww[u], a.H, a.W)) ? dcn_sample(plane, a.H, a.W, hh[u], ww[u]) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = k0 + u < K ? k0 + u : K - 1;
+        const float val = vv[u];
+        const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OC);
+#pragma unroll
+        for (int o = 0; o < OC / 4; ++o) {
+          const float4 w4 = wk[o];
+          acc[4 * o] = fmaf(w4.x, val, acc[4 * o]);
+          acc[4 * o + 1] = fmaf(w4.y, val, acc[4 * o + 1]);
+          acc[4 * o + 2] = fmaf(w4.z, val, acc[4 * o + 2]);
+          acc[4 * o + 3] = fmaf(w4.w, val, acc[4 * o + 3]);
+        }
       }
     }
   }
