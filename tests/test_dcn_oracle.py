@@ -107,3 +107,30 @@ def test_module_surface_without_gpu():
     p = DeformConvPack(4, 4, 3, 1, 1)
     assert float(p.conv_offset.weight.abs().max()) == 0.0 and p.conv_offset.lr_mult == 0.1
     assert list(p.state_dict()) == ['weight', 'bias', 'conv_offset.weight', 'conv_offset.bias']
+
+
+@pytest.mark.parametrize('DG,stride,pad,dil', [(1, 1, 1, 1), (2, 2, 1, 1), (4, 1, 2, 2)])
+def test_vectorised_oracle_equals_the_reference_loops(DG, stride, pad, dil):
+    """oracle/dcn_loops.py restates the reference's three device loops index by index (column layout,
+    offset channel order, `> -1` / `<= -1` boundary rules, C-style int() truncation in col2im): the vectorised
+    oracle must agree with it on columns, input gradient and offset gradient."""
+    from oracle import dcn_loops as L
+    rng = np.random.default_rng(13 + DG)
+    B, C, H, W, kh, kw = 2, 4, 5, 4, 3, 3
+    st, pd, dl = (stride, stride), (pad, pad), (dil, dil)
+    Ho, Wo = D._out_size(H, W, kh, kw, st, pd, dl)
+    im = rng.standard_normal((B, C, H, W))
+    off = rng.standard_normal((B, DG * 2 * kh * kw, Ho, Wo)) * 2
+    off[0, 0, 0, 0] = -50.0                              # far outside
+    off[0, 1, 0, 0] = -1.0 - (0 * st[1] - pd[1])         # w_im exactly -1: excluded by the `> -1` rule
+    cols = L.columns(im, off, kh, kw, st, pd, dl, DG)                      # [C*K][B][Ho][Wo]
+    mine = D.deform_columns(im, off, kh, kw, st, pd, dl, DG)               # [B][C][K][Ho][Wo]
+    assert np.abs(cols.reshape(C, kh * kw, B, Ho, Wo).transpose(2, 0, 1, 3, 4) - mine).max() < 1e-12
+    # gradients with groups=1, identity-like use of the backward: feed a random column gradient through both
+    Co = 3
+    wgt = rng.standard_normal((Co, C, kh, kw))
+    go = rng.standard_normal((B, Co, Ho, Wo))
+    gi, goff, _, _ = D.deform_conv_backward(im, off, wgt, go, st, pd, dl, 1, DG)
+    gcol = np.einsum('ok,bop->kbp', wgt.reshape(Co, -1), go.reshape(B, Co, -1)).reshape(C * kh * kw, B, Ho, Wo)
+    assert np.abs(L.col2im(gcol, off, im.shape, kh, kw, st, pd, dl, DG) - gi).max() < 1e-10
+    assert np.abs(L.col2im_coord(gcol, im, off, kh, kw, st, pd, dl, DG) - goff).max() < 1e-10
