@@ -1,6 +1,8 @@
 """GPU parity of the individual HIP kernels (called through the C ABI) against plain torch
 fp32 on the CPU. fp32 device path: <= 1e-4 relative (exact f32 MFMA, only summation order
 differs); bf16 path: <= 3e-2 relative (bf16 operands, f32 accumulation)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -545,6 +547,24 @@ def test_device_side_targets_and_normalisation_match_the_host_pipeline():
     ref = (u8.float() / 255.0 - torch.tensor(synth.IMAGENET_MEAN)) / torch.tensor(synth.IMAGENET_STD)
     out = normalize_u8(u8.cuda()).cpu()
     assert float((out - ref.permute(0, 3, 1, 2)).abs().max()) <= 1e-6
+
+
+def test_decode_and_softmax_kernels_against_the_reference_centre_of_mass(golden_dir):
+    """the HIP expectation decode and spatial-softmax kernels vs the reference's integrate_tensor_2d fixture"""
+    from hipnet import _capi as C
+    from utils.heatmap_decoding import get_final_preds
+    g = np.load(os.path.join(golden_dir, 'decode_crosscheck.npz'))
+    d = 'cuda:0'
+    pos = torch.from_numpy(g['pos']).to(d)
+    got = get_final_preds(pos, use_softmax=True).cpu().numpy()
+    assert np.abs(got - g['coords_normalised']).max() <= 2e-5
+    raw = torch.from_numpy(g['raw']).to(d)
+    one = torch.ones(1, device=d)
+    soft = torch.empty_like(raw)
+    C.call('hrnet_spatial_softmax_fwd', raw.data_ptr(), one.data_ptr(), soft.data_ptr(), 63, 480, C.stream_ptr())
+    assert np.abs(soft.cpu().numpy() - g['softmax_maps']).max() <= 1e-7
+    got2 = get_final_preds(soft, use_softmax=True).cpu().numpy()
+    assert np.abs(got2 - g['coords_softmax']).max() <= 2e-5
 
 
 def test_adam_step_matches_torch():

@@ -147,3 +147,16 @@ def test_softmax_head_variant_matches_reference_fixture(golden_dir):
         err = np.abs(sd[k].grad.numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)
         assert err <= 5e-2, (k, err)          # the fixture is fp32: the chaotic-gradient band
     assert list(g['state_keys_head'])[0] == 'trainable_temp'
+
+
+def test_expectation_decode_cross_checked_by_the_reference_centre_of_mass(golden_dir):
+    """kornia (the reference's decode) is unavailable; the reference's own integrate_tensor_2d
+    (triangulation_model_utils/op.py:11-47) gives the same numbers on normalised maps and, with softmax=True,
+    pins the softmax-head + expectation chain of pose_hrnet_softmax."""
+    g = np.load(os.path.join(golden_dir, 'decode_crosscheck.npz'))
+    got = O.get_final_preds(torch.from_numpy(g['pos']), use_softmax=True).numpy()
+    assert np.abs(got - g['coords_normalised']).max() <= 2e-5
+    soft = torch.softmax(torch.from_numpy(g['raw']).reshape(3, 21, -1), dim=2).reshape(3, 21, 24, 20)
+    assert np.abs(soft.numpy() - g['softmax_maps']).max() <= 1e-7
+    got2 = O.get_final_preds(soft, use_softmax=True).numpy()
+    assert np.abs(got2 - g['coords_softmax']).max() <= 2e-5
