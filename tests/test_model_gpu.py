@@ -278,6 +278,25 @@ def test_w48_non_square_forward_matches_oracle():
     assert np.abs(hm.cpu().numpy() - ref_hm.numpy()).max() <= 1e-3 * max(1.0, np.abs(ref_hm.numpy()).max())
 
 
+def test_w48_eval_forward_matches_reference_fixture(golden_dir):
+    """config 4 geometry at its real size (384x288), fp32 device path, against the reference's own w48 module"""
+    from hipnet import synth
+    g = np.load(os.path.join(golden_dir, 'w48_eval_b1.npz'))
+    stats = {k[5:]: g[k] for k in g.files if k.startswith('stat.')}
+    model, _, _ = make_model('fp32', 6, stats, yaml=YAML48)
+    assert sum(p.numel() for p in model.parameters()) == int(g['n_params'])
+    model.eval()
+    x = torch.from_numpy(synth.rhd_batch(1, seed=2, img_h=384, img_w=288)['imgs']).cuda()
+    with torch.no_grad():
+        hm, _ = model(x)
+    assert tuple(hm.shape) == (1, 21, 96, 72)
+    ref = g['plain.heatmaps_slice']
+    got = hm[0, :, 40, 20:44].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    a = hm.double().cpu().reshape(-1)
+    np.testing.assert_allclose([a.sum().item(), a.abs().sum().item()], g['plain.heatmaps_checksum'][:2], rtol=1e-3)
+
+
 def test_w48_training_step_matches_oracle_fp64():
     """config 4 channels (48/96/192/384: Cin not a multiple of the K chunk, 720-wide head), non-square
     192x160 crops, B=2, fp32 device path: loss, heat maps and every gradient in the fp32 oracle's band."""

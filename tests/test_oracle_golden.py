@@ -160,3 +160,36 @@ def test_expectation_decode_cross_checked_by_the_reference_centre_of_mass(golden
     assert np.abs(soft.numpy() - g['softmax_maps']).max() <= 1e-7
     got2 = O.get_final_preds(soft, use_softmax=True).numpy()
     assert np.abs(got2 - g['coords_softmax']).max() <= 2e-5
+
+
+def _w48_extra():
+    extra = dict(O.W32_EXTRA)
+    for s_, ch in ((2, [48, 96]), (3, [48, 96, 192]), (4, [48, 96, 192, 384])):
+        extra['STAGE{}'.format(s_)] = dict(O.W32_EXTRA['STAGE{}'.format(s_)], NUM_CHANNELS=ch)
+    return extra
+
+
+def test_w48_eval_forward_matches_reference_fixture(golden_dir):
+    """BASELINE config 4 geometry (48/96/192/384 channels, 384x288): the oracle against the reference's own
+    pose_hrnet and pose_hrnet_softmax modules (tests/golden/make_golden_w48.py)."""
+    g = np.load(os.path.join(golden_dir, 'w48_eval_b1.npz'))
+    extra = _w48_extra()
+    tmpl = O.state_template(extra)
+    assert sum(int(np.prod(v)) for k, v in tmpl.items()
+               if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))) == int(g['n_params'])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(tmpl, 6).items()}
+    for k in g.files:
+        if k.startswith('stat.'):
+            sd[k[5:]] = torch.from_numpy(g[k])
+    x = torch.from_numpy(synth.rhd_batch(1, seed=2, img_h=384, img_w=288)['imgs'])
+    with torch.no_grad():
+        hm, _, _ = O.hrnet_forward(sd, extra, x, training=False)
+        assert tuple(hm.shape) == tuple(g['plain.shape']) == (1, 21, 96, 72)
+        np.testing.assert_allclose(hm[0, :, 40, 20:44].numpy(), g['plain.heatmaps_slice'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(_checksum(hm)[:2], g['plain.heatmaps_checksum'][:2], rtol=2e-4)
+        # (the generator filled the temperature from the same keyed PRNG as every other entry)
+        sd['trainable_temp'] = torch.from_numpy(np.asarray(synth.fill_state_dict({'trainable_temp': ()}, 6)['trainable_temp']))
+        sd['last_layer.1.running_mean'] = torch.from_numpy(g['softmax.stat.last_layer.1.running_mean'])
+        sd['last_layer.1.running_var'] = torch.from_numpy(g['softmax.stat.last_layer.1.running_var'])
+        hs, _, _ = O.hrnet_forward(sd, extra, x, training=False, softmax_head=True)
+        np.testing.assert_allclose(hs[0, :, 40, 20:44].numpy(), g['softmax.heatmaps_slice'], rtol=1e-3, atol=1e-8)
