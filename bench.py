@@ -290,8 +290,7 @@ def main():
     opt = FlatAdam(model, lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
     sync = None
     if world > 1:
-        sync = GradSync(model)
-        opt.grad_scale = 1.0 / world
+        sync = GradSync(model, optimizer=opt)
 
     if args.mode == 'infer':
         return infer_main(args, model, x, world, rank, dev)

@@ -23,6 +23,16 @@ extern "C" int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks
   return choose_tile(N, Ho, Wo, Cout, ks, stride, true, ks == 3 && stride == 2).gx;
 }
 
+// the tile walk a conv launch of this shape takes: out5 = {tile height, tile width, output-channel block,
+// pixel tiles per workgroup, pixel walks}; returns the number of pixel tiles (tests assert that the
+// multi-tile walk, tiles-per-workgroup >= 2, is what they exercise)
+extern "C" int hrnet_conv_tile_walk(int N, int Ho, int Wo, int Cout, int ks, int stride, int bwdstats, int s2d,
+                                    int* out5) {
+  const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, bwdstats != 0, s2d != 0);
+  if (out5) { out5[0] = tc.th; out5[1] = tc.tw; out5[2] = tc.bn; out5[3] = tc.tpw; out5[4] = tc.gx; }
+  return N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
+}
+
 int hr_launch_conv(const HrOp& op, hipStream_t s) {
   const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cin = op.i[4], Ho = op.i[5],
             Wo = op.i[6], Cout = op.i[7], ks = op.i[8], upz = op.i[10];

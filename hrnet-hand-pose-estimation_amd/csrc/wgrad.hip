@@ -298,6 +298,12 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   return ns;
 }
 
+// pixel tiles a weight-gradient launch walks (each of the hrnet_wgrad_splits() splits takes tiles/splits of them)
+extern "C" int hrnet_wgrad_tiles(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride) {
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);
+  return N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
+}
+
 int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cin = op.i[4], Ho = op.i[5],
             Wo = op.i[6], Cout = op.i[7], ks = op.i[8], stride = op.i[9], nsplit = op.i[11];

@@ -110,9 +110,14 @@ def train_helper(epoch, i, args, config, master, ret, model, optimizer, dataset_
     imgs, loss_dict = _forward_and_losses(config, ret, model, recorder, device)
     total_loss = loss_dict['total_loss']
     optimizer.zero_grad()
-    if fp16:
-        optimizer.backward(total_loss)
+    if fp16 and hasattr(optimizer, 'backward'):
+        optimizer.backward(total_loss)          # an apex-style FP16_Optimizer wrapper (reference function.py:101-104)
     else:
+        if fp16 and not getattr(train_helper, '_fp16_warned', False):
+            train_helper._fp16_warned = True
+            logger.warning('FP16.ENABLED is accepted but has no effect here: there is no loss scaling on this path; '
+                           'reduced precision is MODEL.COMPUTE_DTYPE: bf16 (bf16 MFMA, f32 accumulation and '
+                           'master weights)')
         total_loss.backward()
     sync = getattr(model, '_segment_hook', None)
     if sync is not None:

@@ -171,6 +171,29 @@ class Program(object):
         return len(self.ops)
 
 
+class PlanTicket(object):
+    """held by the autograd node of one training forward: marks the plan busy until the backward has run or the
+    graph is dropped (then the node, and with it this ticket, is garbage-collected)"""
+
+    def __init__(self, plan):
+        self.plan, self.gen = plan, plan.gen
+        plan.busy = True
+
+    def valid(self):
+        return self.plan.gen == self.gen
+
+    def release(self):
+        if self.plan is not None and self.plan.gen == self.gen:
+            self.plan.busy = False
+        self.plan = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class Plan(object):
     """Forward (+ backward) programs of one (batch, height, width, mode) instance."""
 
@@ -205,6 +228,8 @@ class Plan(object):
         self.wlane = 4 if (self.nlanes > 1 and wl in ('1', '2')) else 0
         self.wlane_all = wl == '1'
         self.streams = None
+        self.gen = 0              # bumped by every forward run: a backward must see the generation it recorded
+        self.busy = False         # a training forward ran and its backward has not (PlanTicket)
         self._build()
 
     # ---- allocation helpers -----------------------------------------------------------
@@ -729,6 +754,7 @@ class Plan(object):
 
     # ---- execution --------------------------------------------------------------------------
     def run_forward(self, x):
+        self.gen += 1
         N = self.N
         oa, ia = self.out_act, self.inter_act
         hm = torch.empty((N, self.nj, oa.H, oa.W), dtype=torch.float32, device=self.dev)
@@ -745,7 +771,7 @@ class Plan(object):
             # d(inter_feat) joins the gradient of stage3's branch-0 output before its consumers'
             # contributions are read: run up to that op, add it, continue
             cut = self.inter_gop
-            self.bwd.run(0, cut, streams=self._side_streams())
+            self._run_segments(0, cut, segment_hook, last=False)     # stage 4's buckets are exchanged on the way
             ia = self.inter_act
             tmp = torch.empty(ia.N * ia.H * ia.W * ia.C * self.esize, dtype=torch.uint8, device=self.dev)
             C.call('hrnet_nchw_to_nhwc', self.dtid, g_inter.data_ptr(), tmp.data_ptr(), ia.N, ia.H, ia.W, ia.C,
@@ -756,16 +782,17 @@ class Plan(object):
         else:
             self._run_segments(0, len(self.bwd), segment_hook)
 
-    def _run_segments(self, lo, hi, hook):
+    def _run_segments(self, lo, hi, hook, last=True):
         streams = self._side_streams()
         if hook is None:
             self.bwd.run(lo, hi, streams=streams)
             return
-        cuts = [c for c in hook.cuts if lo < c < hi]
+        cuts = [c for c in hook.cuts if lo < c <= hi and (c < hi or not last)]
         prev = lo
         for c in cuts:
             self.bwd.run(prev, c, streams=streams)
             hook.after(c)
             prev = c
         self.bwd.run(prev, hi, streams=streams)
-        hook.after(hi)
+        if last:
+            hook.after(hi)

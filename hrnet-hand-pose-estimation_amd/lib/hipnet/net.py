@@ -110,12 +110,23 @@ class HipNet(object):
         self.fwd_packed = self.bwd_packed = False
 
     # ---- forward / backward -------------------------------------------------------------------
+    MAX_PLANS_IN_FLIGHT = 4
+
     def plan(self, N, H, W, training, need_grad):
+        """the cached plan of this shape. A plan owns its activation / gradient buffers, so a training forward
+        whose backward has not run yet keeps it busy: a second forward of the same shape in between (gradient
+        accumulation over summed losses, siamese / consistency losses) gets its own plan instead of overwriting
+        the activations the first graph's backward will read."""
         key = (N, H, W, bool(training), bool(need_grad))
-        p = self.plans.get(key)
-        if p is None:
-            p = Plan(self, N, H, W, training, need_grad)
-            self.plans[key] = p
+        pool = self.plans.setdefault(key, [])
+        for p in pool:
+            if not (need_grad and p.busy):
+                return p
+        if len(pool) >= self.MAX_PLANS_IN_FLIGHT:
+            raise RuntimeError('pose_hrnet: {} training forwards of shape {} are waiting for their backward; run '
+                               'backward (or drop the outputs) before more forwards'.format(len(pool), (N, H, W)))
+        p = Plan(self, N, H, W, training, need_grad)
+        pool.append(p)
         return p
 
     def forward(self, x, training, need_grad):
@@ -130,6 +141,9 @@ class HipNet(object):
         plan = self.plan(N, H, W, training, need_grad)
         hm, inter = plan.run_forward(x)
         return hm, inter, plan
+
+    def all_plans(self):
+        return [p for pool in self.plans.values() for p in pool]
 
     def prepare_grads(self):
         """PyTorch semantics for .grad: None -> fresh, ours -> accumulate, a foreign tensor (autograd

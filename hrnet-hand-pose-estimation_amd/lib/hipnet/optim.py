@@ -3,10 +3,12 @@
 FlatAdam   torch.optim.Adam semantics (lib/utils/utils.py:81-85: lr, L2 weight decay added to the
            gradient; betas (0.9, 0.999), eps 1e-8) as ONE fused HIP kernel over the flat f32 master
            parameters instead of 921 per-tensor updates.
-GradSync   replaces DistributedDataParallel's reducer (tools/train.py:239-244): sum-all-reduce of
-           the flat gradient over RCCL, issued bucket by bucket while the backward program is
-           still running (gradients complete in reverse layer order = descending flat offsets),
-           the 1/world_size average folded into the optimizer's gradient scale.
+GradSync   replaces DistributedDataParallel's reducer (tools/train.py:239-244): parameters and buffers
+           are broadcast from rank 0 when it is installed (as DDP's constructor does), then every step
+           a sum-all-reduce of the flat gradient over RCCL, issued bucket by bucket while the backward
+           program is still running (gradients complete in reverse layer order = descending flat
+           offsets). The 1/world_size average is folded into FlatAdam's gradient scale when that is the
+           optimizer; with any other optimizer finish() scales the flat gradient itself.
 """
 import torch
 
@@ -48,6 +50,7 @@ class FlatAdam(object):
         net.mark_weights_dirty()
 
     def state_dict(self):
+        self._state()            # the moment buffers are created lazily: a checkpoint before the first step has zeros
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
                 'param_groups': self.param_groups}
 
@@ -65,7 +68,7 @@ class GradSync(object):
     Installed as `model._segment_hook`; engine.Plan._run_segments calls `after(op_index)` right
     after enqueueing a backward segment."""
 
-    def __init__(self, model, bucket_bytes=16 << 20, process_group=None):
+    def __init__(self, model, optimizer=None, bucket_bytes=16 << 20, process_group=None, broadcast=True):
         import torch.distributed as dist
         self.dist = dist
         self.pg = process_group
@@ -76,7 +79,30 @@ class GradSync(object):
         self._ranges = {}
         self._works = []
         self._plan = None
+        self._done = set()
+        self.scale_in_finish = True
         model._segment_hook = self
+        if optimizer is not None:
+            self.attach(optimizer)
+        if broadcast:
+            self.broadcast_state()
+
+    def attach(self, optimizer):
+        """fold the 1/world average into the optimizer when it can take it (FlatAdam.grad_scale); otherwise
+        finish() divides the reduced gradient (torch.optim.SGD / AdamW / HRNET_TORCH_OPTIM=1)"""
+        if hasattr(optimizer, 'grad_scale'):
+            optimizer.grad_scale = 1.0 / self.world
+            self.scale_in_finish = False
+        else:
+            self.scale_in_finish = True
+
+    def broadcast_state(self, src=0):
+        """every replica starts from rank `src`'s parameters and BatchNorm buffers (DDP's constructor semantics)"""
+        net = self.model.hip()
+        self.dist.broadcast(net.flat_p, src, group=self.pg)
+        for b in self.model.buffers():
+            self.dist.broadcast(b, src, group=self.pg)
+        net.mark_weights_dirty()
 
     def _prepare(self, plan):
         net = plan.net
@@ -105,17 +131,27 @@ class GradSync(object):
         if self._plan is not plan:
             self._prepare(plan)
         self._works = []
+        self._done = set()
 
     def after(self, op_index):
         net = self._plan.net
         rng = self._ranges.get(op_index)
         if rng is None and op_index == self._end:
             rng = self._tail
-        if rng is None or rng[1] <= rng[0]:
+        if rng is None or rng[1] <= rng[0] or op_index in self._done:
             return
+        self._done.add(op_index)
         self._works.append(self.dist.all_reduce(net.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
 
     def finish(self):
+        """wait for the exchanges of this step; any bucket whose mark the backward run did not pass (it was
+        executed in pieces around an external gradient) is exchanged now, so no range stays rank-local"""
+        if self._plan is not None:
+            for op_index in list(self._ranges) + [self._end]:
+                if op_index not in self._done:
+                    self.after(op_index)
         for w in self._works:
             w.wait()
         self._works = []
+        if self.scale_in_finish and self._plan is not None and self.world > 1:
+            self._plan.net.flat_g.mul_(1.0 / self.world)

@@ -23,6 +23,7 @@ import os
 import torch
 import torch.nn as nn
 
+from hipnet.engine import PlanTicket
 from hipnet.net import HipNet
 
 BN_MOMENTUM = 0.1
@@ -207,7 +208,10 @@ class PoseHighResolutionNet(nn.Module):
 
     def forward(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
-            raise RuntimeError('pose_hrnet: input must be a tensor on the HIP device; this build has no CPU path')
+            raise RuntimeError('pose_hrnet: input must be a tensor on the HIP device - move the model and the input '
+                               'with .cuda() first (callers that run a CPU forward before .cuda(), like the '
+                               "reference's get_model_summary at tools/train.py:196-200, must do it after); "
+                               'this build has no CPU path')
         net = self.hip()
         x = x.contiguous().float()
         if self.training and torch.is_grad_enabled():
@@ -251,12 +255,16 @@ class _HRNetFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         hm, inter, plan = net.forward(x, training=True, need_grad=True)
         ctx.net, ctx.plan = net, plan
+        ctx.ticket = PlanTicket(plan)
         ctx.hook = getattr(module, '_segment_hook', None)
         return hm, inter
 
     @staticmethod
     def backward(ctx, g_hm, g_inter):
         plan = ctx.plan
+        if ctx.ticket is None or not ctx.ticket.valid():
+            raise RuntimeError('pose_hrnet: the activations of this forward pass are gone (backward already ran '
+                               'for it, or another forward reused its buffers); call forward again')
         if g_hm is None:
             g_hm = torch.zeros((plan.N, plan.nj, plan.out_act.H, plan.out_act.W), dtype=torch.float32,
                                device=plan.dev)
@@ -264,6 +272,8 @@ class _HRNetFunction(torch.autograd.Function):
         if g_inter is not None:
             g_inter = g_inter.contiguous().float()
         ctx.net.backward(plan, g_hm, g_inter, ctx.hook)
+        ctx.ticket.release()
+        ctx.ticket = None
         return None, None, None
 
 

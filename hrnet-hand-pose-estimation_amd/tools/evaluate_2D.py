@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from config import cfg, update_config
+from core.evaluate2d import Eval2DAccumulator, load_checkpoint_state
 from dataset.build import make_dataloader
 from models import pose_hrnet, pose_hrnet_softmax  # noqa: F401
 from utils.heatmap_decoding import get_final_preds
@@ -41,20 +42,18 @@ def main():
     torch.cuda.set_device(device)
     model = eval(cfg.MODEL.NAME + '.get_pose_net')(cfg, is_train=False)
     if args.model_path:
-        sd = torch.load(args.model_path, map_location='cpu')
-        sd = sd.get('state_dict', sd)
-        model.load_state_dict({k[7:] if k.startswith('module.') else k: v for k, v in sd.items()}, strict=True)
+        load_checkpoint_state(model, args.model_path)
     model = model.to(device).eval()
     c = cfg.clone()
     c.defrost()
     c.TEST.IMAGES_PER_GPU = args.batch_size
     loader = list(make_dataloader(c, False, num_batches=args.num_batches).values())[0]
     K = cfg.MODEL.NUM_JOINTS
-    scale = cfg.MODEL.IMAGE_SIZE[0] / cfg.MODEL.HEATMAP_SIZE[0]
-    thresholds = np.arange(1, 50)
     # accumulators and file formats of the reference (tools/evaluate_2D.py:166-169,270-294): per-joint error
-    # sums, PCK counted with a strict `<` over all visible joints, PCK2d.txt = two rows (thresholds, PCK)
-    err_sum, vis_sum, pck_hits = np.zeros(K), np.zeros(K), np.zeros(len(thresholds))
+    # sums, PCK counted with a strict `<` over all visible joints, PCK2d.txt = two rows (thresholds, PCK);
+    # coordinates are scaled from heat-map pixels to the input crop (:241-245 with orig size = crop size)
+    acc = Eval2DAccumulator(K, cfg.MODEL.HEATMAP_SIZE[0])
+    crop = (cfg.MODEL.IMAGE_SIZE[0], cfg.MODEL.IMAGE_SIZE[1])
     timed, t_total = 0, 0.0
     with torch.no_grad():
         for i, ret in enumerate(loader):
@@ -67,21 +66,11 @@ def main():
             if i >= 20 or i >= len(loader) // 2:
                 t_total += time.time() - t0
                 timed += imgs.shape[0]
-            pred = pred.cpu().numpy() * scale
-            gt = ret['pose2d'].numpy() * scale
-            vis = ret['visibility'].numpy().reshape(imgs.shape[0], K).astype(np.float64)
-            epe = np.linalg.norm(pred - gt, axis=2)
-            err_sum += (epe * vis).sum(0)
-            vis_sum += vis.sum(0)
-            pck_hits += ((epe[None] * vis[None] < thresholds[:, None, None]) * vis[None]).sum((1, 2))
+            acc.add(pred.cpu().numpy(), ret['pose2d'].numpy(), ret['visibility'].numpy(), orig_size=crop)
     out_dir = os.path.join(cfg.OUTPUT_DIR or 'output', 'eval2D_results_' + cfg.EXP_NAME)
-    os.makedirs(out_dir, exist_ok=True)
-    mse_each = err_sum / np.maximum(vis_sum, 1)
-    pck = pck_hits / max(vis_sum.sum(), 1)
-    np.savetxt(os.path.join(out_dir, 'mse2d_each_joint.txt'), mse_each, fmt='%.4f')
-    np.savetxt(os.path.join(out_dir, 'PCK2d.txt'), np.stack((thresholds, pck)))
+    mse_each, pck = acc.save(out_dir)
     print('fps: {:.1f}'.format(timed / max(t_total, 1e-9)))
-    print('mean EPE {:.3f} px  PCK@20px {:.4f}  AUC(1-49px) {:.4f}'.format(mse_each.mean(), pck[19], pck.mean()))
+    print('mean EPE {:.3f} px  PCK@20px {:.4f}  AUC(1-49px) {:.4f}'.format(np.nanmean(mse_each), pck[1, 19], pck[1].mean()))
 
 
 if __name__ == '__main__':

@@ -63,9 +63,10 @@ def main():
         begin_epoch, best_perf = ckpt['epoch'], ckpt.get('loss', best_perf)
         logger.info('=> resumed from {} (epoch {})'.format(ckpt_file, begin_epoch))
     model = model.to(device)
+    sync = None
     if world > 1:
         from hipnet.optim import GradSync
-        GradSync(model)
+        sync = GradSync(model)        # broadcasts rank 0's parameters / buffers, as DDP's constructor does
 
     criterion = {}
     if cfg.LOSS.WITH_HEATMAP_LOSS:
@@ -73,8 +74,8 @@ def main():
     if cfg.LOSS.WITH_POSE2D_LOSS:
         criterion['pose2d_loss'] = JointsMSELoss().to(device)
     optimizer = get_optimizer(cfg, model)
-    if world > 1 and hasattr(optimizer, 'grad_scale'):
-        optimizer.grad_scale = 1.0 / world
+    if sync is not None:
+        sync.attach(optimizer)        # 1/world: folded into FlatAdam, applied in finish() for torch optimizers
     if ckpt is not None and 'optimizer' in ckpt:
         optimizer.load_state_dict(ckpt['optimizer'])
     writer_dict = {'writer': None, 'train_global_steps': 0, 'valid_global_steps': 0}

@@ -132,6 +132,10 @@ int hrnet_wgrad_kernel_name(int dtype, int Ho, int Wo, int Cout, int Cin, int ks
                             int buflen);
 /* number of per-tile stat rows hrnet_conv2d writes for this shape */
 int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int stride);
+/* the tile walk of a conv launch: out5 = {tile h, tile w, output-channel block, pixel tiles per workgroup,
+ * pixel walks (= statistics rows)}; returns the number of pixel tiles. s2d = the four-parity input gradient
+ * of a 3x3 stride-2 conv (upz with hrnet_conv2d_bwdstats or a plain input-gradient launch). */
+int hrnet_conv_tile_walk(int N, int Ho, int Wo, int Cout, int ks, int stride, int bwdstats, int s2d, int* out5);
 /* rows of a hrnet_conv2d_bwdstats launch (its tile choice differs for wide 1x1 outputs) */
 int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks, int stride);
 
@@ -145,6 +149,8 @@ int hrnet_conv2d_wgrad(int dtype, const void* x, const void* dy, const float* in
                        int Wo, int Cout, int ks, int stride, int in_relu, int nsplit,
                        hr_stream_t stream);
 int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
+/* pixel tiles the launch walks in all (a split takes tiles / nsplit of them, grid-strided) */
+int hrnet_wgrad_tiles(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
 /* slabs -> grad_oihw[Cout_real][Cin_real][ks][ks] f32 (+= if accumulate). Cout/Cin are the
  * padded slab extents; stem: kflat=1 means slab K index is the flattened (tap,ci) of the
  * im2col'ed stem (Cin_real*ks*ks real entries). */

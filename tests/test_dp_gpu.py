@@ -1,6 +1,8 @@
 """Data-parallel gradient exchange on the real backward program: 2 ranks (both on cuda:0, gloo carrying
-the CUDA tensors) - the bucketed, overlapped all-reduce must leave exactly the sum of the ranks' local
-gradients in the flat gradient buffer (the RCCL run at N>1 is the driver's)."""
+the CUDA tensors) - installing GradSync broadcasts rank 0's parameters / buffers to ranks that started
+from different ones, and the bucketed, overlapped all-reduce must leave exactly the mean of the ranks' local
+gradients in the flat gradient buffer (torch.optim.SGD has no gradient scale to fold 1/world into), also when
+a gradient on inter_feat splits the backward run in two (the RCCL run at N>1 is the driver's)."""
 import os
 import sys
 
@@ -32,29 +34,45 @@ def _worker(rank, world, port, q):
         cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_max_hmloss_v1.yaml'))
         cfg.MODEL.COMPUTE_DTYPE = 'fp32'
         model = pose_hrnet.get_pose_net(cfg, is_train=False)
-        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(model.state_dict(), 2).items()}
+        # every rank starts from DIFFERENT weights and BatchNorm buffers: installing GradSync must make them rank 0's
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(model.state_dict(), 2 + rank).items()}
         model.load_state_dict(sd)
         model = model.cuda().train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)              # no grad_scale: finish() must average
+        sync = GradSync(model, optimizer=opt, bucket_bytes=8 << 20)    # small buckets: several overlapped exchanges
+        net = model.hip()
+        ps = [torch.empty_like(net.flat_p) for _ in range(world)]
+        dist.all_gather(ps, net.flat_p)
+        rv = [torch.empty_like(model.bn1.running_var) for _ in range(world)]
+        dist.all_gather(rv, model.bn1.running_var)
+        ref0 = torch.from_numpy(np.asarray(synth.fill_for_key('conv2.weight', tuple(model.conv2.weight.shape), 2))).cuda()
+        same = bool(torch.equal(ps[0], ps[1]) and torch.equal(rv[0], rv[1]) and torch.equal(model.conv2.weight.detach(), ref0))
         b = synth.rhd_batch(2, seed=40 + rank, img_h=128, img_w=128)
         x, gt = torch.from_numpy(b['imgs']).cuda(), torch.from_numpy(b['heatmaps']).cuda()
         crit = HeatmapLoss()
-
-        def run():
-            model.zero_grad()
-            crit(model(x)[0], gt).backward()
-        run()                                             # local gradient, no exchange
-        net = model.hip()
-        local = net.flat_g.clone()
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local)
-        want = parts[0] + parts[1]
-        sync = GradSync(model, bucket_bytes=8 << 20)      # small buckets: several overlapped exchanges
-        run()
-        sync.finish()
-        torch.cuda.synchronize()
-        got = net.flat_g
-        ok = bool(torch.equal(got, want))
-        q.put((rank, ok, len(sync.cuts), float((got - want).abs().max())))
+        errs = []
+        for with_inter in (False, True):
+            def run():
+                model.zero_grad()
+                hm, inter = model(x)
+                loss = crit(hm, gt)
+                if with_inter:
+                    loss = loss + inter.square().mean()     # a gradient on inter_feat: backward runs in two pieces
+                loss.backward()
+            model._segment_hook = None
+            run()                                             # local gradient, no exchange
+            local = net.flat_g.clone()
+            parts = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            want = (parts[0] + parts[1]) * (1.0 / world)
+            model._segment_hook = sync
+            run()
+            sync.finish()
+            torch.cuda.synchronize()
+            got = net.flat_g
+            errs.append(float((got - want).abs().max()))
+            same = same and bool(torch.equal(got, want))
+        q.put((rank, same, len(sync.cuts), errs))
         dist.destroy_process_group()
     except Exception as e:   # surface the failure in the parent
         import traceback

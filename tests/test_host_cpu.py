@@ -154,14 +154,34 @@ def _gradsync_worker(rank, world, port, q):
     plan.net = net
     plan.bwd = list(range(60))
     plan.bucket_marks = [((6 - i) * 10, 'l{}'.format(i)) for i in range(5, -1, -1)]   # op index after layer i
-    sync = GradSync(FakeModel(), bucket_bytes=8000)       # 2 layers per bucket
+    class FakeFlatAdam:
+        grad_scale = 1.0
+    total = float(sum(range(1, world + 1)))
+    # (1) an optimizer that takes the 1/world factor itself (FlatAdam): the buffer keeps the SUM
+    opt = FakeFlatAdam()
+    sync = GradSync(FakeModel(), optimizer=opt, bucket_bytes=8000, broadcast=False)       # 2 layers per bucket
     sync.begin(plan)
     cuts = list(sync.cuts)
     # engine.Plan._run_segments: hook.after(c) for every cut strictly inside, then after(end)
     for c in [c for c in cuts if 0 < c < len(plan.bwd)] + [len(plan.bwd)]:
         sync.after(c)
     sync.finish()
-    ok = bool(torch.all(net.flat_g == float(sum(range(1, world + 1)))))
+    ok = bool(torch.all(net.flat_g == total)) and opt.grad_scale == 1.0 / world
+    # (2) any other optimizer (torch.optim.SGD ...): finish() leaves the MEAN, as DDP does
+    net.flat_g.fill_(float(rank + 1))
+    sync = GradSync(FakeModel(), optimizer=object(), bucket_bytes=8000, broadcast=False)
+    sync.begin(plan)
+    for c in [c for c in sync.cuts if 0 < c < len(plan.bwd)] + [len(plan.bwd)]:
+        sync.after(c)
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
+    # (3) a backward that never passed the bucket marks (run in pieces around an external gradient): finish()
+    # still exchanges every range exactly once
+    net.flat_g.fill_(float(rank + 1))
+    sync.begin(plan)
+    sync.after(sync.cuts[0])
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
     q.put((rank, ok, cuts))
     dist.destroy_process_group()
 

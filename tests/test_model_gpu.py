@@ -212,6 +212,43 @@ def test_gradient_accumulation_and_zero_grad_semantics():
     assert torch.allclose(p.grad, g1, rtol=1e-5, atol=1e-7)
 
 
+def test_two_forwards_before_their_backwards_keep_separate_activations():
+    """a plan owns its activation buffers: a second training forward of the same shape before the first one's
+    backward (summed micro-batch losses, siamese / consistency losses) must not overwrite what that backward reads"""
+    from hipnet import synth
+    from core.loss import HeatmapLoss
+    model, _, _ = make_model('fp32', 2)
+    model.train()
+    b1 = synth.rhd_batch(2, seed=3, img_h=64, img_w=64)
+    b2 = synth.rhd_batch(2, seed=4, img_h=64, img_w=64)
+    x1, g1 = torch.from_numpy(b1['imgs']).cuda(), torch.from_numpy(b1['heatmaps']).cuda()
+    x2, g2 = torch.from_numpy(b2['imgs']).cuda(), torch.from_numpy(b2['heatmaps']).cuda()
+    crit = HeatmapLoss()
+    p = model.stage2[0].branches[0][0].conv1.weight
+    # sequential reference: gradients of the two batches, accumulated
+    crit(model(x1)[0], g1).backward()
+    crit(model(x2)[0], g2).backward()
+    want = p.grad.clone()
+    model.zero_grad(set_to_none=True)
+    # both forwards first, ONE backward of the summed loss
+    l1 = crit(model(x1)[0], g1)
+    l2 = crit(model(x2)[0], g2)
+    assert len(model.hip().plans[(2, 64, 64, True, True)]) == 2
+    (l1 + l2).backward()
+    assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-7)
+    assert not any(pl.busy for pl in model.hip().all_plans())
+    # a dropped graph frees its plan; a retained graph cannot run backward twice on recycled buffers
+    l3 = crit(model(x1)[0], g1)
+    del l3
+    import gc
+    gc.collect()
+    assert not any(pl.busy for pl in model.hip().all_plans())
+    l4 = crit(model(x1)[0], g1)
+    l4.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='activations of this forward pass are gone'):
+        l4.backward()
+
+
 def test_optimizer_step_changes_output_and_inter_feat_gradient_path():
     from hipnet import synth
     model, _, _ = make_model('fp32', 4)
