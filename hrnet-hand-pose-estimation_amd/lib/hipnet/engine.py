@@ -326,9 +326,12 @@ class Plan(object):
     def _build(self):
         net = self.net
         N, H, W = self.N, self.H, self.W
-        cv, bn = net.convs, net.bns
+        # BatchNorm coefficient buffers (scale/shift/mean/invstd/coef) belong to the PLAN: two plans of one net
+        # can be in flight at once (hipnet.net.HipNet.plan), and each backward needs its own forward's statistics
+        self.bns = {name: BNRec(name, rec.mod, self.dev) for name, rec in net.bns.items()}
+        cv, bn = net.convs, self.bns
         if not self.training:
-            for b in net.bn_list:
+            for b in self.bns.values():
                 m = b.mod
                 self.fwd.add(C.OP_BN_FINALIZE, ints=(0, b.C, 0), floats=(1.0, 0.1, m.eps),
                              ptrs=(None, C.ptr(m.weight), C.ptr(m.bias), C.ptr(m.running_mean),
@@ -395,7 +398,7 @@ class Plan(object):
 
     def _hr_module(self, xs, pre, num_blocks):
         """HighResolutionModule.forward, pose_hrnet.py:247-266."""
-        cv, bn = self.net.convs, self.net.bns
+        cv, bn = self.net.convs, self.bns
         nb = len(xs)
         xs = list(xs)
         side = [i for i in range(1, nb) if i < self.nlanes]

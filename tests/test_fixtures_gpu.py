@@ -75,7 +75,7 @@ def test_reference_dataparallel_checkpoint_loads_strict(tmp_path, wrapped):
     assert torch.equal(a, b)
     # a checkpoint with a missing or unexpected entry is refused (strict)
     bad = dict(sd)
-    bad.pop(keys[5])
+    bad.pop('module.stage3.1.branches.2.0.conv1.weight')
     torch.save(bad, path)
     with pytest.raises(RuntimeError, match='Missing key'):
         load_checkpoint_state(_model(), path)
