@@ -77,6 +77,10 @@ def conv_flops_table(plan):
                 C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[4], op.i[7], op.i[8],
                        op.i[9], op.i[10], mode, buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, False))
+            elif op.kind == C.OP_BWD_FUSED:
+                # weight gradient + input gradient of one 3x3 conv in one launch: 2 x the forward conv's FLOPs
+                C.call('hrnet_bwd_fused_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
+                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5] * 9)
             elif op.kind == C.OP_WGRAD:
                 C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[4], op.i[8], op.i[9], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, True))
@@ -93,7 +97,7 @@ def traffic_of(kernel_name):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    m = re.match(r'(conv_bs|conv_fwdb|conv_fwd|conv_dg|conv|wgrad)_kernel<[^,]+, (.*)>', kernel_name)
+    m = re.match(r'(conv_bs|conv_fwdb|conv_fwd|conv_dg|conv|wgrad|bwd_fused)_kernel<[^,]+, (.*)>', kernel_name)
     if not m:
         return None
     key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])

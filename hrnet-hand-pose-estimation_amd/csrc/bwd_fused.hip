@@ -1,0 +1,652 @@
+// Fused backward of a 3x3 stride-1 convolution whose output feeds a BatchNorm, for gfx950.
+//
+// One launch does what the unfused backward does in four (grad_term, wgrad, conv_bs, and the
+// gradient-side half of the residual add):
+//
+//   g[p,co]   = A[co]*dz[p,co] + B[co]*y[p,co] + C[co]           BatchNorm backward applied while the
+//                                                                output-side tile is staged into LDS
+//                                                                (dz = upstream gradient, already masked
+//                                                                by its ReLU; y = raw conv output)
+//   dW[co,t,ci] += sum_p g[p,co] * a[p+t,ci]                     weight gradient (pixels = K, transposing
+//                                                                LDS reads of the SAME two images)
+//   v[p,ci]   = sum_{t,co} Wt[ci,t,co] * g[p+t,co] (+ addend)    input gradient (+ the residual stream)
+//   dx[p,ci]  = v * [a[p,ci] > 0]                                masked by the ReLU in front of the conv:
+//                                                                what is stored IS the next dz
+//   rows      = (sum dx, sum dx*yb)                              statistics of the next BatchNorm backward
+//
+// a = relu?(scale*x+shift) is the conv's input as the forward pass saw it (staged once, used as the
+// weight-gradient operand AND as the mask). Per 16x16 pixel tile the kernel reads three halo images
+// (dz, y, x) and writes one tile: ~4.8 tensor passes where the unfused sequence makes ~11, and the
+// MFMA work per staged byte doubles.
+//
+// Geometry: 512 threads (8 waves), one workgroup per CU, 16x16 tiles, all Cout (<= 64) channels of the
+// output side staged, one 32-channel block of the input side per workgroup (its slice of dW stays in
+// registers across the tiles the workgroup walks -> one f32 slab per workgroup, summed by
+// hrnet_wgrad_reduce(_table) like the unfused slabs). The next tile's global loads are issued into
+// registers before the MFMAs of the current one.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+struct BwdArgs {
+  const char* dz;        // [N,H,W,Cout] upstream gradient w.r.t. the BatchNorm output, ReLU mask applied
+  const char* y;         // [N,H,W,Cout] raw conv output
+  const float* coef;     // [3][Cout] A,B,C of hrnet_bn_bwd_finalize, or NULL: g = dz
+  const char* x;         // [N,H,W,Cin] conv input as stored
+  const float* in_scale; // optional per-Cin affine (+ReLU) the forward applied on load
+  const float* in_shift;
+  const char* wT;        // packed [Cin][9 flipped][Cout] (hrnet_pack_weights mode 1)
+  char* dx;              // [N,H,W,Cin] out
+  const char* addend;    // optional [N,H,W,Cin] added before the mask (may alias dx)
+  const char* bs_y;      // optional [N,H,W,Cin]: rows get sum(dx*bs_y)
+  float* rows;           // optional [nsplit][2][Cin]
+  float* slabs;          // [nsplit][Cout][9][Cin] f32
+  int N, H, W, Cin, Cout;
+  int tiles_y, tiles_x, total_tiles;
+  int ncb, nsplit;
+  int in_relu, mask_out;
+  unsigned long long* stamp;   // measurement only (HRNET_FUSED_STAMP_PTR): 32 s_memtime stamps per workgroup
+  int ablate;   // measurement only (HRNET_FUSED_ABLATE): 1 skip input-gradient MFMAs, 2 skip weight-gradient MFMAs, 4 skip the
+                // epilogue's global traffic, 8 skip the tile loads (stage zeros)
+};
+
+template <typename T>
+__device__ __forceinline__ V16 trl(const char* base, int r0, int rstep, int choff, int lane);
+template <>
+__device__ __forceinline__ V16 trl<bf16_t>(const char* base, int r0, int rstep, int choff, int lane) {
+  const int q = (lane & 15) >> 2, p4 = lane & 3;
+  const int addr = r0 + q * rstep + choff + p4 * 8;
+  const LDS_AS char* l = (const LDS_AS char*)base;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + addr));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + addr + 4 * rstep));
+  const bf16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(V16, v);
+}
+template <>
+__device__ __forceinline__ V16 trl<float>(const char* base, int r0, int rstep, int choff, int lane) {
+  const char* p = base + r0 + choff + (lane & 15) * 4;
+  return V16{*(const uint32_t*)p, *(const uint32_t*)(p + rstep), *(const uint32_t*)(p + 2 * rstep),
+             *(const uint32_t*)(p + 3 * rstep)};
+}
+
+// COP: staged output-side channels (Cout padded to 32 or 64). WCO x WN = 8 waves over the weight-gradient
+// outputs: WCO co-halves x WN groups of (tap, ci-fragment).
+// YLDS: the raw conv output y of the NEXT tile is parked in LDS instead of registers while it is in flight
+// (direct global->LDS loads, each lane reads back exactly the 16 bytes it requested): 24 fewer live VGPRs.
+// TH: tile height (tile width 16). NW: waves per workgroup (NW*64 threads): 8 waves = one workgroup per CU;
+// 4 waves = two or three co-resident workgroups per CU, each with its own tile in flight, so that one
+// workgroup's load waits overlap another's matrix work.
+template <typename T, int COP, int TH, int NW, int WCO, int WN, bool YLDS>
+__global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  constexpr int KSTEP = TT<T>::KSTEP;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int NT = NW * 64;
+  constexpr int TW = 16, HALO = 18, HALO_H = TH + 2, HPX = HALO_H * HALO, BM = TH * TW;
+  constexpr int PW = BM / NW, FP = PW / 16;    // input-gradient pixels / pixel fragments per wave
+  constexpr int CB = 32;                       // input-side channels per workgroup
+  constexpr int GPIX = COP * ES + 16;          // padded pixel strides (bytes)
+  constexpr int APIX = CB * ES + 16;
+  constexpr int WROW = 9 * COP * ES + 16;      // one row = one input channel: [tap][co]
+  constexpr int GBYTES = HPX * GPIX, ABYTES = HPX * APIX, WBYTES = CB * WROW;
+  constexpr int VPG = COP / VEC, VPA = CB / VEC;     // 16-byte vectors per pixel
+  constexpr int GVECS = HPX * VPG, AVECS = HPX * VPA, WVECS = CB * 9 * VPG;
+  constexpr int XG = (GVECS + NT - 1) / NT, XA = (AVECS + NT - 1) / NT, XW = (WVECS + NT - 1) / NT;
+  constexpr int FCO = COP / 16;                // co fragments
+  constexpr int FCOW = FCO / WCO;              // ... per wave (weight gradient)
+  constexpr int NFR = 9 * (CB / 16);           // (tap, ci-fragment) outputs = 18
+  constexpr int NPW = (NFR + WN - 1) / WN;
+  static_assert(WCO * WN == NW && FCO % WCO == 0 && PW % 16 == 0, "wave grid");
+  static_assert(NT % VPG == 0 && NT % VPA == 0, "a thread keeps one channel vector");
+  constexpr int YBYTES = YLDS ? XG * NT * 16 : 0;   // one 16-byte slot per (thread, k): lane-linear
+  constexpr int CBYTES = (3 * COP + 2 * CB) * 4;     // per-channel coefficient tables: A, B, C | scale, shift
+  static_assert(GBYTES + ABYTES + WBYTES + YBYTES + CBYTES <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char lds[GBYTES + ABYTES + WBYTES + YBYTES + CBYTES];
+  char* gl = lds;
+  char* al = lds + GBYTES;
+  char* wl = lds + GBYTES + ABYTES;
+  char* yl = lds + GBYTES + ABYTES + WBYTES;
+  float* ctab = (float*)(lds + GBYTES + ABYTES + WBYTES + YBYTES);   // [A COP][B COP][C COP][scale CB][shift CB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  // workgroup -> (split, input-channel block): the ncb blocks of one split get ids 8 apart (same XCD: they
+  // stage the same output-side tiles)
+  const int grp = blockIdx.x / (8 * a.ncb), r8 = blockIdx.x % (8 * a.ncb);
+  const int cb = r8 / 8;
+  const int split = grp * 8 + (r8 & 7);
+  if (split >= a.nsplit) return;
+  const int c0 = cb * CB;
+  int stamp_i = 0;
+#define FSTAMP() do { if (a.stamp && tid == 0 && stamp_i < 32) a.stamp[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+  FSTAMP();
+
+  // ---- weights of this input-channel block: resident for the whole walk ----
+  {
+    const int v = tid % VPG;
+#pragma unroll
+    for (int k = 0; k < XW; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < WVECS) {
+        const int rt = idx / VPG;
+        const int tp = rt % 9, q = rt / 9;          // LDS row q holds the channel the MFMA row order needs
+        const int ci = c0 + ((q & 15) >> 2) * 8 + (q >> 4) * 4 + (q & 3);
+        const int co = v * VEC;
+        V16 w = v16_zero();
+        if (ci < a.Cin && co < a.Cout) w = *(const V16*)(a.wT + ((size_t)(ci * 9 + tp) * a.Cout + co) * ES);
+        *(V16*)(wl + q * WROW + (tp * COP) * ES + v * 16) = w;
+      }
+    }
+  }
+
+  FSTAMP();
+  // coefficient tables (read back per tile: a dependent global load inside the staging pass costs its full latency)
+  for (int i = tid; i < 3 * COP + 2 * CB; i += NT) {
+    float v = 0.f;
+    if (i < 3 * COP) {
+      const int w = i / COP, c = i % COP;
+      if (a.coef && c < a.Cout) v = a.coef[w * a.Cout + c];
+    } else {
+      const int j = i - 3 * COP, w = j / CB, c = c0 + j % CB;
+      v = w == 0 ? 1.f : 0.f;
+      if (a.in_scale && c < a.Cin) v = w == 0 ? a.in_scale[c] : a.in_shift[c];
+    }
+    ctab[i] = v;
+  }
+  __syncthreads();   // the first staging pass reads the tables
+  const int vg = tid % VPG, va = tid % VPA;
+  const int cg = vg * VEC, ca = c0 + va * VEC;
+  const bool cg_ok = cg < a.Cout, ca_ok = ca < a.Cin;
+  const bool has_coef = a.coef != nullptr, has_aff = a.in_scale != nullptr, in_relu = a.in_relu != 0;
+
+  V16 rz[XG], ry[XG], rx[XA];
+  unsigned okg = 0, oka = 0;
+
+  auto tile_of = [&](int t, int& n, int& ty, int& tx) {
+    tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    ty = t % a.tiles_y;
+    n = t / a.tiles_y;
+  };
+
+  // per-thread staging geometry is the same for every tile: the halo coordinates of each staged vector and its
+  // byte offset from the tile's first halo pixel are computed once; per tile two adds and two unsigned compares
+  // per vector remain (the address is a wave-uniform base + a 32-bit lane offset)
+  const int rowG = a.W * a.Cout * ES, pixG = a.Cout * ES, rowA = a.W * a.Cin * ES, pixA = a.Cin * ES;
+  int hyxg[XG], offg[XG], hyxa[XA], offa[XA];
+#pragma unroll
+  for (int k = 0; k < XG; ++k) {
+    const int pix = (tid + k * NT) / VPG;
+    const int hy = pix / HALO, hx = pix - hy * HALO;
+    hyxg[k] = (tid + k * NT) < GVECS && cg_ok ? (hy << 16) | hx : (0x4000 << 16);    // invalid: row far outside
+    offg[k] = hy * rowG + hx * pixG + cg * ES;
+  }
+#pragma unroll
+  for (int k = 0; k < XA; ++k) {
+    const int pix = (tid + k * NT) / VPA;
+    const int hy = pix / HALO, hx = pix - hy * HALO;
+    hyxa[k] = (tid + k * NT) < AVECS && ca_ok ? (hy << 16) | hx : (0x4000 << 16);
+    offa[k] = hy * rowA + hx * pixA + ca * ES;
+  }
+
+  // the next tile's loads are issued in NS steps spread over the nine taps of the input-gradient loop instead of
+  // in one burst: a burst of ~100 KB per CU stalls the issuing waves on the CU's miss queue (~2.5 us per tile
+  // measured) and leaves the memory pipe idle during the matrix phases
+  const char *bz = nullptr, *by = nullptr, *bx = nullptr;   // wave-uniform bases of the tile being loaded
+  int liy0 = 0, lix0 = 0;
+  auto load_begin = [&](int t) {
+    int n, ty, tx;
+    tile_of(t, n, ty, tx);
+    n = __builtin_amdgcn_readfirstlane(n); ty = __builtin_amdgcn_readfirstlane(ty); tx = __builtin_amdgcn_readfirstlane(tx);
+    liy0 = ty * TH - 1; lix0 = tx * TW - 1;
+    // (image n, halo origin); may point before the image (masked lanes never load)
+    bz = a.dz + (ptrdiff_t)n * a.H * rowG + (ptrdiff_t)liy0 * rowG + (ptrdiff_t)lix0 * pixG;
+    by = a.y + (ptrdiff_t)n * a.H * rowG + (ptrdiff_t)liy0 * rowG + (ptrdiff_t)lix0 * pixG;
+    bx = a.x + (ptrdiff_t)n * a.H * rowA + (ptrdiff_t)liy0 * rowA + (ptrdiff_t)lix0 * pixA;
+    okg = oka = 0;
+  };
+  auto load_g = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int gy = liy0 + (hyxg[k] >> 16), gx = lix0 + (hyxg[k] & 0xffff);
+    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    // branch-free: these loads are issued between the transposing LDS reads of the matrix phases, which need
+    // every lane active (ds_read_b64_tr_b16 is a cross-lane gather); lanes outside the image read the tensor's
+    // first bytes and are zeroed when the tile is staged
+    const int o = ok ? offg[k] : 0;
+    rz[k] = *(const V16*)((ok ? bz : a.dz) + o);
+    if (has_coef) {
+      if constexpr (YLDS) {
+        // destination = wave-uniform base + lane * 16: slot (tid + k*NT) of the y image
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((ok ? by : a.y) + o),
+                                         (__attribute__((address_space(3))) void*)(yl + ((tid & ~63) + k * NT) * 16),
+                                         16, 0, 0);
+      } else {
+        ry[k] = *(const V16*)((ok ? by : a.y) + o);
+      }
+    }
+    okg |= (ok ? 1u : 0u) << k;
+  };
+  auto load_a = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int gy = liy0 + (hyxa[k] >> 16), gx = lix0 + (hyxa[k] & 0xffff);
+    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    rx[k] = *(const V16*)((ok ? bx : a.x) + (ok ? offa[k] : 0));
+    oka |= (ok ? 1u : 0u) << k;
+  };
+  constexpr int NS = XG + XA;
+  constexpr int NSLOT = 9 + (BM / KSTEP <= 8 ? BM / KSTEP : 0);   // issue slots: the 9 taps (+ the weight-gradient k-steps)
+  auto load_step = [&](auto sc) {       // step s < XG: dz + y vector s; else x vector s - XG
+    constexpr int s_ = decltype(sc)::value;
+    if constexpr (s_ < XG) load_g(std::integral_constant<int, s_>{});
+    else if constexpr (s_ < NS) load_a(std::integral_constant<int, s_ - XG>{});
+  };
+  auto load_steps = [&](auto lo, auto hi) {
+    constexpr int L = decltype(lo)::value, Hh = decltype(hi)::value;
+    if constexpr (L < Hh) {
+      load_step(std::integral_constant<int, L>{});
+      if constexpr (L + 1 < Hh) load_step(std::integral_constant<int, L + 1>{});
+      if constexpr (L + 2 < Hh) load_step(std::integral_constant<int, L + 2>{});
+      if constexpr (L + 3 < Hh) load_step(std::integral_constant<int, L + 3>{});
+      static_assert(Hh - L <= 4, "at most four steps per tap");
+    }
+  };
+  auto load_tile = [&](int t) {         // all at once (the first tile)
+    load_begin(t);
+    load_steps(std::integral_constant<int, 0>{}, std::integral_constant<int, (NS > 4 ? 4 : NS)>{});
+    if constexpr (NS > 4) load_steps(std::integral_constant<int, 4>{}, std::integral_constant<int, (NS > 8 ? 8 : NS)>{});
+    if constexpr (NS > 8) load_steps(std::integral_constant<int, 8>{}, std::integral_constant<int, (NS > 12 ? 12 : NS)>{});
+    if constexpr (NS > 12) load_steps(std::integral_constant<int, 12>{}, std::integral_constant<int, NS>{});
+    static_assert(NS <= 16, "staging steps");
+  };
+
+  auto store_tile = [&]() {
+    if constexpr (YLDS) {
+      // the direct-to-LDS loads of this wave have landed (each lane reads only its own slots)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < XG; ++k)
+        if (has_coef && ((okg >> k) & 1u)) ry[k] = *(const V16*)(yl + (tid + k * NT) * 16);
+    }
+    if (has_coef) {
+      float cA[VEC], cB[VEC], cC[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        cA[j] = ctab[cg + j];
+        cB[j] = ctab[COP + cg + j];
+        cC[j] = ctab[2 * COP + cg + j];
+      }
+#pragma unroll
+      for (int k = 0; k < XG; ++k) {
+        if ((okg >> k) & 1u) {          // outside the image the gradient is zero, not B*0+C
+          float fz[VEC], fy[VEC];
+          v16_unpack<T>(rz[k], fz);
+          v16_unpack<T>(ry[k], fy);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) fz[j] = fmaf(cA[j], fz[j], fmaf(cB[j], fy[j], cC[j]));
+          rz[k] = v16_pack<T>(fz);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XG; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < GVECS) *(V16*)(gl + (idx / VPG) * GPIX + vg * 16) = ((okg >> k) & 1u) ? rz[k] : v16_zero();
+    }
+    if (has_aff || in_relu) {
+      float sc[VEC], sh[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        sc[j] = ctab[3 * COP + va * VEC + j];
+        sh[j] = ctab[3 * COP + CB + va * VEC + j];
+      }
+#pragma unroll
+      for (int k = 0; k < XA; ++k) {
+        if ((oka >> k) & 1u) {          // zero padding is applied AFTER the transform, as the forward did
+          float f[VEC];
+          v16_unpack<T>(rx[k], f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            f[j] = fmaf(f[j], sc[j], sh[j]);
+            if (in_relu) f[j] = f[j] > 0.f ? f[j] : 0.f;
+          }
+          rx[k] = v16_pack<T>(f);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XA; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < AVECS) *(V16*)(al + (idx / VPA) * APIX + va * 16) = ((oka >> k) & 1u) ? rx[k] : v16_zero();
+    }
+  };
+
+  // ---- per-lane operand offsets ----
+  // input gradient D[ci 32][pixel 256]: a wave owns 32 pixels (2 fragments) x all 32 channels (2 fragments);
+  // a lane ends up with 8 contiguous channels of one pixel per pixel fragment
+  int aoff[2], boff[FP];
+#pragma unroll
+  for (int fc = 0; fc < 2; ++fc) aoff[fc] = (fc * 16 + li) * WROW + lg * 16;
+#pragma unroll
+  for (int fp = 0; fp < FP; ++fp) {
+    const int p = wave * PW + fp * 16 + li;
+    boff[fp] = ((p / TW) * HALO + (p % TW)) * GPIX + lg * 16;
+  }
+  // weight gradient: this wave's co fragments and (tap, ci-fragment) list
+  const int wco = wave % WCO, wn = wave / WCO;
+  f32x4 accw[NPW][FCOW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j)
+#pragma unroll
+    for (int f = 0; f < FCOW; ++f) accw[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+
+  const int ci0 = c0 + lg * 8;             // this lane's 8 output channels of the input gradient
+  const bool ci_ok = ci0 < a.Cin;
+  constexpr int EV = 8 * ES / 16;          // 16-byte vectors of 8 channels: 1 (bf16) or 2 (f32)
+
+  int t = split;
+  if (t < a.total_tiles) load_tile(t);
+  if (a.ablate & 8) { okg = oka = 0; }
+  FSTAMP();
+  for (; t < a.total_tiles; t += a.nsplit) {
+    FSTAMP();
+    store_tile();
+    FSTAMP();
+    __syncthreads();
+    FSTAMP();
+    const bool has_next = t + a.nsplit < a.total_tiles && !(a.ablate & 8);
+    if (has_next) load_begin(t + a.nsplit);
+    int n, ty, tx;
+    tile_of(t, n, ty, tx);
+    n = __builtin_amdgcn_readfirstlane(n); ty = __builtin_amdgcn_readfirstlane(ty); tx = __builtin_amdgcn_readfirstlane(tx);
+    // epilogue operands of this tile (addend, next BatchNorm's raw input), fetched before the matrix work
+    const size_t img = (size_t)n * a.H * rowA;
+    V16 pa[FP][EV], pb[FP][EV];
+    bool pok[FP];
+    int poff[FP];
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+      const int p = wave * PW + fp * 16 + li;
+      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+      pok[fp] = ci_ok && oy < a.H && ox < a.W && !(a.ablate & 4);
+      poff[fp] = (oy * a.W + ox) * pixA + ci0 * ES;          // within image n
+#pragma unroll
+      for (int q = 0; q < EV; ++q) {
+        pa[fp][q] = v16_zero();
+        pb[fp][q] = v16_zero();
+        if (pok[fp]) {
+          if (a.addend) pa[fp][q] = *(const V16*)(a.addend + img + poff[fp] + q * 16);
+          if (a.bs_y) pb[fp][q] = *(const V16*)(a.bs_y + img + poff[fp] + q * 16);
+        }
+      }
+    }
+
+    FSTAMP();
+    // ---- input gradient: conv of g with the transposed, flipped kernel ----
+    f32x4 accd[2][FP];
+#pragma unroll
+    for (int fc = 0; fc < 2; ++fc)
+#pragma unroll
+      for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(a.ablate & 1))
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int tapb = ((tp / 3) * HALO + (tp % 3)) * GPIX;
+#pragma unroll
+      for (int kk = 0; kk < COP / KSTEP; ++kk) {
+        constexpr int KB = KSTEP * ES;
+        V16 af[2], bf[FP];
+#pragma unroll
+        for (int fc = 0; fc < 2; ++fc) af[fc] = *(const V16*)(wl + aoff[fc] + (tp * COP) * ES + kk * KB);
+#pragma unroll
+        for (int fp = 0; fp < FP; ++fp) bf[fp] = *(const V16*)(gl + boff[fp] + tapb + kk * KB);
+#pragma unroll
+        for (int fc = 0; fc < 2; ++fc)
+#pragma unroll
+          for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = mma16<T>(af[fc], bf[fp], accd[fc][fp]);
+      }
+      // this tap's share of the next tile's loads; vector-memory instructions may not move across (everything
+      // else may): the requests enter the memory pipe evenly while the matrix pipe works
+      __builtin_amdgcn_sched_barrier(0x38F);
+      if (has_next) {
+        switch (tp) {
+#define LS(SL) case SL: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
+          LS(0) LS(1) LS(2) LS(3) LS(4) LS(5) LS(6) LS(7) LS(8)
+#undef LS
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0x38F);
+    }
+
+    FSTAMP();
+    // ---- weight gradient: pixels are the contraction index; both operands come transposed out of the
+    // images staged above (center pixels of g, tap-shifted pixels of a) ----
+#pragma unroll
+    for (int ks = 0; ks < BM / KSTEP; ++ks) {
+      if constexpr (BM / KSTEP <= 8) {
+        if (has_next) {
+          switch (ks) {
+#define LS(SL) case SL - 9: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
+            LS(9) LS(10) LS(11) LS(12) LS(13) LS(14) LS(15) LS(16)
+#undef LS
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0x38F);
+      }
+      const int p0 = ks * KSTEP + lg * VEC;
+      const int py = p0 / TW, px = p0 % TW;
+      const int gr0 = ((py + 1) * HALO + px + 1) * GPIX;
+      V16 af[FCOW];
+#pragma unroll
+      for (int f = 0; f < FCOW; ++f) af[f] = trl<T>(gl, gr0, GPIX, (wco * FCOW + f) * 16 * ES, lane);
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        const int fr = wn + WN * j;
+        if (fr < NFR) {
+          const int tp = fr / (CB / 16), cf = fr % (CB / 16);
+          const V16 bf = trl<T>(al, ((py + tp / 3) * HALO + px + tp % 3) * APIX, APIX, cf * 16 * ES, lane);
+#pragma unroll
+          for (int f = 0; f < FCOW; ++f) accw[j][f] = mma16<T>(af[f], bf, accw[j][f]);
+        }
+      }
+    }
+
+    FSTAMP();
+    // ---- tile epilogue: residual addend, ReLU mask from the staged input image, store, statistics ----
+#pragma unroll
+    for (int fp = 0; fp < FP; ++fp) {
+      const int p = wave * PW + fp * 16 + li;
+      float v[8];
+      v[0] = accd[0][fp].x; v[1] = accd[0][fp].y; v[2] = accd[0][fp].z; v[3] = accd[0][fp].w;
+      v[4] = accd[1][fp].x; v[5] = accd[1][fp].y; v[6] = accd[1][fp].z; v[7] = accd[1][fp].w;
+      if (pok[fp]) {
+        if (a.addend) {
+          float ad[8];
+#pragma unroll
+          for (int q = 0; q < EV; ++q) v16_unpack<T>(pa[fp][q], ad + q * VEC);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += ad[k];
+        }
+        if (a.mask_out) {
+          float am[8];
+          const char* ap = al + ((p / TW + 1) * HALO + (p % TW) + 1) * APIX + lg * 8 * ES;
+#pragma unroll
+          for (int q = 0; q < EV; ++q) v16_unpack<T>(*(const V16*)(ap + q * 16), am + q * VEC);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = am[k] > 0.f ? v[k] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < EV; ++q) *(V16*)(a.dx + img + poff[fp] + q * 16) = v16_pack<T>(v + q * VEC);
+        if (a.rows) {
+          float yb[8];
+#pragma unroll
+          for (int q = 0; q < EV; ++q) v16_unpack<T>(pb[fp][q], yb + q * VEC);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            s1[k] += v[k];
+            s2[k] = fmaf(v[k], yb[k], s2[k]);
+          }
+        }
+      }
+    }
+    FSTAMP();
+    __syncthreads();   // the images are free again
+  }
+  FSTAMP();
+
+  // ---- backward statistics: lanes -> waves -> one row per workgroup (deterministic) ----
+  if (a.rows) {
+    float* sl = (float*)lds;   // [NW waves][2][32]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s1[k] = wave_sum16(s1[k]);
+      s2[k] = wave_sum16(s2[k]);
+    }
+    if (li == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sl[(wave * 2 + 0) * CB + lg * 8 + k] = s1[k];
+        sl[(wave * 2 + 1) * CB + lg * 8 + k] = s2[k];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CB) {
+      const int which = tid / CB, cl = tid % CB;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) s += sl[(q * 2 + which) * CB + cl];
+      if (c0 + cl < a.Cin) a.rows[((size_t)split * 2 + which) * a.Cin + c0 + cl] = s;
+    }
+  }
+
+  FSTAMP();
+  // ---- weight-gradient slab of this workgroup: slab[split][co][tap][ci], D: col = ci, row = co ----
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int fr = wn + WN * j;
+    if (fr < NFR) {
+      const int tp = fr / (CB / 16), ci = c0 + (fr % (CB / 16)) * 16 + li;
+#pragma unroll
+      for (int f = 0; f < FCOW; ++f) {
+        const int co = (wco * FCOW + f) * 16 + lg * 4;
+        const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * 9 + tp) * a.Cin + ci] = v4[r];
+      }
+    }
+  }
+  FSTAMP();
+}
+
+struct FusedCfg {
+  int cop, th, nw, wco, wn, ylds, per_cu;   // per_cu: co-resident workgroups per CU (LDS-limited)
+};
+
+// Variant: 0 = 16x16 tiles, 8 waves, one workgroup per CU; 1 = 16x16 tiles, 4 waves, two per CU;
+// 2 = 8x16 tiles, 4 waves, two or three per CU. (HRNET_FUSED_VARIANT overrides the default for measurements.)
+inline int fused_variant() {
+  static const int v = getenv("HRNET_FUSED_VARIANT") ? atoi(getenv("HRNET_FUSED_VARIANT")) : -1;
+  return v;
+}
+
+inline FusedCfg fused_cfg(int dtype, int Cout) {
+  // 0 in .cop = shape not served by the fused kernel (LDS: 160 KB per CU)
+  const int var = fused_variant();
+  if (dtype == HR_F32) return Cout <= 32 ? FusedCfg{32, 16, 8, 1, 8, 0, 1} : FusedCfg{0, 0, 0, 0, 0, 0, 0};
+  if (Cout <= 32) {
+    if (var == 1) return FusedCfg{32, 16, 4, 1, 4, 0, 2};
+    if (var == 2) return FusedCfg{32, 8, 4, 1, 4, 0, 2};   // (188 VGPRs: two 4-wave workgroups per CU)
+    return FusedCfg{32, 16, 8, 1, 8, 0, 1};
+  }
+  if (Cout <= 64) {
+    if (var == 2) return FusedCfg{64, 8, 4, 2, 2, 0, 2};
+    return FusedCfg{64, 16, 8, 2, 4, 0, 1};
+  }
+  return FusedCfg{0, 0, 0, 0, 0, 0, 0};
+}
+
+}  // namespace
+
+// 1 if hrnet_conv3x3_bwd_fused serves this layer (3x3 stride 1, Cout <= 64 for bf16 / <= 32 for f32)
+extern "C" int hrnet_bwd_fused_supported(int dtype, int Cin, int Cout) {
+  if (dtype != HR_F32 && dtype != HR_BF16) return 0;
+  if (Cin % (dtype == HR_F32 ? 4 : 8) != 0 || Cout % 16 != 0 || Cin <= 0 || Cout <= 0) return 0;
+  return fused_cfg(dtype, Cout).cop != 0 ? 1 : 0;
+}
+
+// number of slabs / statistics rows: one per walk of pixel tiles (a walk is shared by the ceil(Cin/32)
+// workgroups that own its input-channel blocks); the grid fills the CUs once
+extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, int Cout) {
+  const FusedCfg c = fused_cfg(dtype, Cout);
+  if (!c.cop) return 0;
+  const int tiles = N * ((H + c.th - 1) / c.th) * ((W + 15) / 16);
+  const int ncb = (Cin + 31) / 32;
+  int ns = 256 * c.per_cu / ncb;
+  if (ns < 1) ns = 1;
+  if (ns > tiles) ns = tiles;
+  // even walks: every split takes the same number of tiles when possible
+  int even = ns;
+  while (even > 1 && tiles % even != 0) --even;
+  if (even * 2 > ns) ns = even;
+  return ns;
+}
+
+// name of the instantiation hrnet_conv3x3_bwd_fused launches, as rocprofv3 demangles it (returns its length)
+extern "C" int hrnet_bwd_fused_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen) {
+  (void)Cin;
+  const FusedCfg c = fused_cfg(dtype, Cout);
+  return snprintf(buf, buflen, "bwd_fused_kernel<%s, %d, %d, %d, %d, %d, %s>", dtype == HR_F32 ? "float" : "__bf16", c.cop,
+                  c.th, c.nw, c.wco, c.wn, c.ylds ? "true" : "false");
+}
+
+extern "C" int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x,
+                                       const float* in_scale, const float* in_shift, int in_relu, const void* wT,
+                                       void* dx, const void* addend, int mask_out, float* rows, const void* bs_y,
+                                       float* slabs, int N, int H, int W, int Cin, int Cout, hr_stream_t stream) {
+  HR_REQUIRE(hrnet_bwd_fused_supported(dtype, Cin, Cout), "bwd_fused: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
+  HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_fused: null pointer");
+  HR_REQUIRE(!coef || y, "bwd_fused: coef needs y");
+  HR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "bwd_fused: scale/shift must come together");
+  HR_REQUIRE(!bs_y || rows, "bwd_fused: bs_y needs rows");
+  HR_REQUIRE(N > 0 && H > 0 && W > 0, "bwd_fused: empty shape");
+  HR_REQUIRE((double)H * W * (Cin > Cout ? Cin : Cout) * 4.0 < 2147483648.0, "bwd_fused: one image exceeds 2 GiB");
+  const FusedCfg c = fused_cfg(dtype, Cout);
+  BwdArgs a;
+  a.dz = (const char*)dz; a.y = (const char*)y; a.coef = coef; a.x = (const char*)x;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.wT = (const char*)wT; a.dx = (char*)dx;
+  a.addend = (const char*)addend; a.bs_y = (const char*)bs_y; a.rows = rows; a.slabs = slabs;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.tiles_y = (H + c.th - 1) / c.th; a.tiles_x = (W + 15) / 16; a.total_tiles = N * a.tiles_y * a.tiles_x;
+  a.ncb = (Cin + 31) / 32;
+  a.nsplit = hrnet_bwd_fused_splits(dtype, N, H, W, Cin, Cout);
+  a.in_relu = in_relu; a.mask_out = mask_out;
+  { static const char* sp = getenv("HRNET_FUSED_STAMP_PTR"); a.stamp = sp ? (unsigned long long*)strtoull(sp, nullptr, 16) : nullptr; }
+  { static const int abl = getenv("HRNET_FUSED_ABLATE") ? atoi(getenv("HRNET_FUSED_ABLATE")) : 0; a.ablate = abl; }
+  const unsigned grid = (unsigned)((a.nsplit + 7) / 8 * 8 * a.ncb);
+  hipStream_t s = (hipStream_t)stream;
+#define FUSED(T_, COP_, TH_, NW_, WCO_, WN_, Y_) \
+  hipLaunchKernelGGL((bwd_fused_kernel<T_, COP_, TH_, NW_, WCO_, WN_, Y_>), dim3(grid), dim3(NW_ * 64), 0, s, a)
+  if (dtype == HR_F32) FUSED(float, 32, 16, 8, 1, 8, false);
+  else if (c.cop == 32 && c.nw == 8) FUSED(bf16_t, 32, 16, 8, 1, 8, false);
+  else if (c.cop == 32 && c.th == 16) FUSED(bf16_t, 32, 16, 4, 1, 4, false);
+  else if (c.cop == 32) FUSED(bf16_t, 32, 8, 4, 1, 4, false);
+  else if (c.nw == 8) FUSED(bf16_t, 64, 16, 8, 2, 4, false);
+  else FUSED(bf16_t, 64, 8, 4, 2, 2, false);
+#undef FUSED
+  return hr_check_launch("conv3x3_bwd_fused");
+}
+
+int hr_launch_bwd_fused(const HrOp& op, hipStream_t s) {
+  return hrnet_conv3x3_bwd_fused(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4],
+                                 (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7], (float*)op.p[9],
+                                 op.p[10], (float*)op.p[11], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
+}

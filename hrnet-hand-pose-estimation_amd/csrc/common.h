@@ -138,3 +138,4 @@ int hr_launch_bias_grad(const HrOp& op, hipStream_t s);
 int hr_launch_fill(const HrOp& op, hipStream_t s);
 int hr_launch_pack_table(const HrOp& op, hipStream_t s);
 int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s);
+int hr_launch_bwd_fused(const HrOp& op, hipStream_t s);

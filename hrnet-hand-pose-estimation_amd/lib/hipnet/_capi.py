@@ -22,7 +22,7 @@ class HrOp(ctypes.Structure):
                 ('p', ctypes.c_void_p * 14)]
 
 
-OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE = 17, 18, 19, 20
+OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED = 17, 18, 19, 20, 21
 LANE_SLOT = 18
 
 
@@ -58,6 +58,10 @@ _SIGS = {
     'hrnet_conv_kernel_name': [_c_int] * 10 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_kernel_name': [_c_int] * 7 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
+    'hrnet_conv3x3_bwd_fused': [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp],
+    'hrnet_bwd_fused_supported': [_c_int] * 3,
+    'hrnet_bwd_fused_splits': [_c_int] * 6,
+    'hrnet_bwd_fused_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_splits': [_c_int] * 8,
     'hrnet_wgrad_tiles': [_c_int] * 8,
     'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],
@@ -96,7 +100,7 @@ _SIGS = {
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 

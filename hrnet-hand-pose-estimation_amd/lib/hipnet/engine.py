@@ -22,6 +22,10 @@ Scheduling
   Fused BatchNorm-backward sums  the input-gradient conv that writes the LAST contribution to an
          activation gradient gathers (sum dz, sum dz*y) in its epilogue (hrnet_conv2d_bwdstats), which
          replaces the separate reduction pass for ~80 % of the BatchNorms (HRNET_FUSE_BWDSTATS=0: off).
+  Fused block backward  the two 3x3 convs of a BasicBlock whose widths fit (hrnet_bwd_fused_supported) run their
+         whole backward - BatchNorm-backward apply, weight gradient, input gradient, residual add, ReLU mask, the
+         next BatchNorm's sums - as ONE launch each (hrnet_conv3x3_bwd_fused) instead of grad_term + wgrad +
+         conv_bs (HRNET_FUSED_BWD=0: off).
   Batched slab sums  every layer keeps its own weight-gradient slab region; one table-driven launch per
          lane segment sums them (HRNET_BATCH_WRED=0: per-layer launches on shared scratch).
   Bucket marks  op indices at which every gradient above a flat offset is final (module boundaries and
@@ -40,7 +44,7 @@ def _round_up(x, m):
 
 
 class Act(object):
-    __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse', 'bwd_rows')
+    __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse', 'bwd_rows', 'gmasked')
 
     def __init__(self, name, N, H, W, Cc):
         self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cc
@@ -51,6 +55,7 @@ class Act(object):
         self.bn_done = False
         self.nuse = 0       # number of consumers of the logical value
         self.bwd_rows = None  # (rows tensor, nrows): BN-backward sums gathered by a dgrad epilogue
+        self.gmasked = False  # the gradient buffer already carries the ReLU mask of this activation (fused backward)
 
     @property
     def pixels(self):
@@ -539,8 +544,19 @@ class Plan(object):
         self.n_fused_bwdstats = 0
         self.inter_gop = None
         in_region = False
+        self._producer_sum = producer_sum
+        fused_at, fused_skip = self._find_fused_blocks(), set()
+        self.n_fused_blocks = len(fused_at)
         for ti, (e, lane) in reversed(list(enumerate(zip(self.tape, self.tape_lanes)))):
             self.bwd.lane = lane
+            if ti in fused_skip:
+                continue
+            if ti in fused_at:
+                if e[4] is self.inter_act and self.inter_gop is None:
+                    self.inter_gop = len(self.bwd)
+                self._fused_block_backward(ti, lane, in_region)
+                fused_skip.update((ti - 1, ti - 2))
+                continue
             if e[0] in ('fork', 'join'):
                 # a forward join is the backward fork of the same lanes, and vice versa
                 for l in sorted(self._wred):
@@ -680,23 +696,143 @@ class Plan(object):
                                  ptrs=ptrs)
                     x.ginit = True
                 if lane == 0 and not in_region:
-                    if self.batch_wred:
-                        if self._wred_bytes >= (16 << 20):
-                            for l in sorted(self._wred):
-                                self._flush_wred(l)
-                            self.bwd.lane = lane
-                            if self.wlane:
-                                self.bwd.sync(self.wlane, 0)
-                            self.bucket_marks.append((len(self.bwd), crec.prefix))
-                    else:
-                        if self.wlane:
-                            self.bwd.sync(self.wlane, 0)    # this bucket's weight gradients are complete
-                        self.bucket_marks.append((len(self.bwd), crec.prefix))
+                    self._bucket_mark_after_conv(crec)
         if self.batch_wred:
             for l in sorted(self._wred):
                 self._flush_wred(l)
             self.bwd.lane = 0
             self._upload_wred_tables()
+
+    # ---- fused backward of a BasicBlock (conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU: pose_hrnet.py:41-57) ----
+    def _find_fused_blocks(self):
+        """tape indices of the 'sum' entries that close a BasicBlock both of whose convs the fused kernel serves"""
+        out = set()
+        if not self.training or os.environ.get('HRNET_FUSED_BWD', '1') == '0':
+            return out
+        T, L = self.tape, self.tape_lanes
+        maxc = int(os.environ.get('HRNET_FUSED_MAXC', '64'))     # (tests: restrict the fused path to narrow layers)
+        for ti in range(2, len(T)):
+            e = T[ti]
+            if e[0] != 'sum' or T[ti - 1][0] != 'conv' or T[ti - 2][0] != 'conv':
+                continue
+            _, terms, shifts, relu_out, res = e
+            _, xin2, crec2, st2, y2, bn2 = T[ti - 1]
+            _, xin1, crec1, st1, y1, bn1 = T[ti - 2]
+            if not (len(terms) == 2 and list(shifts) == [0, 0] and relu_out and L[ti] == L[ti - 1] == L[ti - 2]):
+                continue
+            c, idt = terms
+            x = xin1.act
+            ok = (c.act is y2 and c.bn is bn2 and bn2 is not None and not c.relu and y2.nuse == 1
+                  and xin2.act is y1 and xin2.bn is bn1 and bn1 is not None and xin2.relu and y1.nuse == 1
+                  and idt.act is x and idt.bn is xin1.bn and idt.relu == xin1.relu and x.nuse == 2
+                  and st1 == 1 and st2 == 1 and crec1.ks == 3 and crec2.ks == 3 and not crec1.stem
+                  and crec1.mod.bias is None and crec2.mod.bias is None and x.g is not None
+                  and max(x.C, y1.C, y2.C) <= maxc
+                  and C.call('hrnet_bwd_fused_supported', self.dtid, x.C, y1.C)
+                  and C.call('hrnet_bwd_fused_supported', self.dtid, y1.C, y2.C))
+            # the mask the kernel applies to the gradient it stores for x is [a > 0], a = the conv's input as staged:
+            # right when x is read through a ReLU, or is the (non-negative) output of a sum that ended in one
+            ps = self._producer_sum.get(id(x))
+            ok = ok and (xin1.relu or (xin1.bn is None and ps is not None and ps[3]))
+            if ok:
+                out.add(ti)
+        return out
+
+    def _bn_bwd_finalize(self, y, reduce_from=None):
+        """coefficients (and dgamma/dbeta) of y's BatchNorm backward from the sums a previous launch left in
+        y.bwd_rows, or from a reduction pass over the (already masked) gradient `reduce_from`"""
+        b, m = y.bn, y.bn.mod
+        tail = (C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd), C.ptr(self.net.grad_of(m.weight)),
+                C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef))
+        if y.bwd_rows is not None:
+            rows, blocks = y.bwd_rows
+            self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,), ptrs=(C.ptr(rows),) + tail)
+        else:
+            blocks = C.call('hrnet_reduce_blocks', y.N, y.H, y.W, y.C)
+            self.max_bwd_part = max(self.max_bwd_part, blocks * 2 * y.C)
+            i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, 0, 0),
+                             ptrs=(None, reduce_from, None, C.ptr(y.t), None, None))
+            self._scratch(self.bwd, i, 0, 'bwdpart')
+            j = self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,), ptrs=(None,) + tail)
+            self._scratch(self.bwd, j, 0, 'bwdpart')
+        y.bn_done = True
+
+    def _fused_conv_bwd(self, dz, y, xin, crec, dx, addend, mask_out, rows_for, lane):
+        """one hrnet_conv3x3_bwd_fused launch: backward of `y = conv(xin)` given the masked gradient `dz` of y's
+        BatchNorm output; writes the gradient of xin's activation into `dx` and y's weight-gradient slabs"""
+        net, x = self.net, xin.act
+        ns = C.call('hrnet_bwd_fused_splits', self.dtid, x.N, x.H, x.W, x.C, y.C)
+        slabs = self._f32(ns * y.C * 9 * x.C)
+        self.slab_bytes += slabs.numel() * 4
+        rows = None
+        if rows_for is not None:
+            rows = self._f32(ns * 2 * x.C)
+            rows_for.bwd_rows = (rows, ns)
+            self.n_fused_bwdstats += 1
+        self.bwd.add(C.OP_BWD_FUSED,
+                     ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0),
+                     ptrs=(dz, C.ptr(y.t), C.ptr(y.bn.coef), C.ptr(x.t),
+                           C.ptr(xin.bn.scale) if xin.bn else None, C.ptr(xin.bn.shift) if xin.bn else None,
+                           C.ptr(crec.wd), dx, addend, C.ptr(rows),
+                           C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs)))
+        w = crec.mod.weight
+        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=3,
+                   Cout=crec.Cout, Cin=crec.Cin, kflat=0, accumulate=1)
+        if self.batch_wred:
+            self._wred.setdefault(lane, []).append(ent)
+            if lane == 0:
+                self._wred_bytes += crec.Cout * crec.Cin * 9 * 4
+        else:
+            self.bwd.add(C.OP_WGRAD_REDUCE, ints=(ns, y.C, x.C, 3, crec.Cout, crec.Cin, 0, 1),
+                         ptrs=(C.ptr(slabs), C.ptr(net.grad_of(w))))
+
+    def _fused_block_backward(self, ti, lane, in_region):
+        _, terms, shifts, relu_out, out = self.tape[ti]
+        _, xin2, crec2, _, y2, bn2 = self.tape[ti - 1]
+        _, xin1, crec1, _, y1, bn1 = self.tape[ti - 2]
+        x = xin1.act
+        if not out.ginit:
+            raise RuntimeError('no gradient reaches ' + out.name)
+        assert not x.ginit and not y1.ginit and not y2.ginit
+        if not out.gmasked:
+            # the block output's gradient came from unfused consumers: apply its ReLU mask once, in place
+            self.bwd.add(C.OP_GRAD_TERM, ints=(self.dtid, out.N, out.H, out.W, out.C, 0, 0, 0, 0),
+                         ptrs=(C.ptr(out.g), C.ptr(out.g), C.ptr(out.t), None, None, None, None, None))
+            out.gmasked = True
+        # conv2: dz = d(out) masked (it is also the identity branch's gradient); its input is relu(bn1(y1))
+        self._bn_bwd_finalize(y2, reduce_from=C.ptr(out.g))
+        self._fused_conv_bwd(C.ptr(out.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane)
+        y1.ginit = y1.gmasked = True
+        y2.ginit = True
+        # conv1: its input is the block input x; the residual stream (the masked d(out)) joins before the mask
+        self._bn_bwd_finalize(y1)
+        target = None
+        if x is not self.inter_act:
+            if xin1.bn is not None:
+                target = x                       # x is a raw conv output read through its BatchNorm + ReLU
+            else:
+                ps = self._producer_sum.get(id(x))
+                cand = [t for t, sh in zip(ps[1], ps[2])
+                        if t.act.bn is not None and t.act.nuse == 1 and sh == 0 and not t.relu] if ps else []
+                target = cand[0].act if cand else None
+        self._fused_conv_bwd(C.ptr(y1.g), y1, xin1, crec1, C.ptr(x.g), C.ptr(out.g), True, target, lane)
+        x.ginit = x.gmasked = True
+        if lane == 0 and not in_region:
+            self._bucket_mark_after_conv(crec1)
+
+    def _bucket_mark_after_conv(self, crec):
+        if self.batch_wred:
+            if self._wred_bytes >= (16 << 20):
+                for l in sorted(self._wred):
+                    self._flush_wred(l)
+                self.bwd.lane = 0
+                if self.wlane:
+                    self.bwd.sync(self.wlane, 0)
+                self.bucket_marks.append((len(self.bwd), crec.prefix))
+        else:
+            if self.wlane:
+                self.bwd.sync(self.wlane, 0)    # this bucket's weight gradients are complete
+            self.bucket_marks.append((len(self.bwd), crec.prefix))
 
     def _flush_wred(self, lane):
         ents = self._wred.pop(lane, None)

@@ -60,7 +60,8 @@ enum {
   HR_OP_PACK_TABLE = 17,
   HR_OP_EVENT_RECORD = 18, /* p[0] = event, recorded on the op's lane */
   HR_OP_STREAM_WAIT = 19,  /* p[0] = event, the op's lane waits for it */
-  HR_OP_WGRAD_REDUCE_TABLE = 20 /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
+  HR_OP_WGRAD_REDUCE_TABLE = 20, /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
+  HR_OP_BWD_FUSED = 21     /* hrnet_conv3x3_bwd_fused */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -157,6 +158,27 @@ int hrnet_wgrad_tiles(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int k
 int hrnet_wgrad_reduce(const float* slabs, float* grad_oihw, int nsplit, int Cout, int Cin,
                        int ks, int Cout_real, int Cin_real, int kflat, int accumulate,
                        hr_stream_t stream);
+
+/*
+ * Fused backward of a 3x3 stride-1 convolution y = conv(a), a = relu?(in_scale*x + in_shift), whose output
+ * feeds a BatchNorm (autograd of the BasicBlock body, pose_hrnet.py:41-57): ONE launch applies the BatchNorm
+ * backward to the upstream gradient while staging it (g = A*dz + B*y + C with coef = [3][Cout] of
+ * hrnet_bn_bwd_finalize; coef NULL: g = dz), forms the weight-gradient slabs (layout and reduction as
+ * hrnet_conv2d_wgrad; nsplit = hrnet_bwd_fused_splits()), the input gradient (+ `addend`, the residual
+ * stream), masks it with [a > 0] when mask_out (so what is stored is the dz of the NEXT BatchNorm backward)
+ * and, when `rows` is given, leaves (sum dx, sum dx*bs_y) per channel in rows[nsplit][2][Cin] for
+ * hrnet_bn_bwd_finalize (bs_y NULL: the second sum is 0).
+ *   dz, y [N,H,W,Cout]; x, dx, addend, bs_y [N,H,W,Cin]; wT = hrnet_pack_weights(mode 1) of the conv.
+ * dz must already carry the ReLU mask of the BatchNorm output it belongs to (an in-place hrnet_grad_term with
+ * coef NULL does that where the producer did not). Served shapes: hrnet_bwd_fused_supported().
+ */
+int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x,
+                            const float* in_scale, const float* in_shift, int in_relu, const void* wT, void* dx,
+                            const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs, int N,
+                            int H, int W, int Cin, int Cout, hr_stream_t stream);
+int hrnet_bwd_fused_supported(int dtype, int Cin, int Cout);
+int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, int Cout);
+int hrnet_bwd_fused_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen);
 
 /*
  * Pack f32 OIHW master weights into the kernels' layout.
