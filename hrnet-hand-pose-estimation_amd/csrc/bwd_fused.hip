@@ -590,7 +590,11 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   if (!c.cop) return 0;
   const int tiles = N * ((H + c.th - 1) / c.th) * ((W + 15) / 16);
   const int ncb = (Cin + 31) / 32;
-  int ns = 256 * c.per_cu / ncb;
+  // half the CUs: measured on MI355X inside the training step (4 lanes in flight), 128 workgroups per launch
+  // beat 256 by 0.6 ms/step (20.6 vs 21.3 ms; 64: 22.0, 96: 22.0, 160: 20.7) - a grid that takes every CU with a
+  // 100 KB / 256-VGPR workgroup locks the other lanes' kernels out - and it halves the slab traffic
+  static const int cus = getenv("HRNET_FUSED_CUS") ? atoi(getenv("HRNET_FUSED_CUS")) : 128;
+  int ns = cus * c.per_cu / ncb;
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   // even walks: every split takes the same number of tiles when possible

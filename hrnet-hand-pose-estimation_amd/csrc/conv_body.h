@@ -19,6 +19,7 @@
 // across waves, one row per workgroup to HBM (deterministic; finished by bn_finalize).
 #pragma once
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -625,10 +626,10 @@ TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool
   // 2 resident workgroups per CU (register-limited) x 256 CUs: a grid of <= 512 workgroups runs as one
   // wave of workgroups with no tail; the rest of the tiles are walked by the same workgroups
   // (measured: 64->64 3x3 @64x64 40.1 us with 512 workgroups, 47.2 us with 683)
-  const int wg_target = 512;
+  static const int wg_target = getenv("HRNET_CONV_WGS") ? atoi(getenv("HRNET_CONV_WGS")) : 512;   // (measurement override)
   int tpw = (tiles2 * gy + wg_target - 1) / wg_target;
   if (tpw < 1) tpw = 1;
-  if (tpw > 8) tpw = 8;
+  if (tpw > 16) tpw = 16;
   tc.tpw = tpw;
   tc.gx = (tiles2 + tpw - 1) / tpw;
   return tc;

@@ -106,6 +106,7 @@ class Program(object):
         self.lane = 0
         self.events = []
         self._arr = None
+        self.tags = {}          # op index -> layer name (measurement scripts only)
 
     def add(self, kind, ints=(), floats=(), ptrs=(), lane=None):
         op = C.HrOp()
@@ -278,6 +279,7 @@ class Plan(object):
                                C.ptr(xin.bn.shift) if xin.bn else None,
                                C.ptr(self.net.bias_pad[crec.prefix]) if bias is not None else None,
                                C.ptr(y.t), None))
+        self.fwd.tags[i] = crec.prefix
         if want_stats:
             self.max_stats = max(self.max_stats, tiles * 2 * crec.Cout_pad)
             self._scratch(self.fwd, i, 6, 'stats')
@@ -621,6 +623,7 @@ class Plan(object):
                 _, xin, crec, stride, y, bnrec = e
                 x = xin.act
                 ks = 1 if crec.stem else crec.ks
+                self.bwd.tags[len(self.bwd)] = crec.prefix
                 if not y.ginit:
                     raise RuntimeError('no gradient reaches ' + y.name)
                 if bnrec is not None and not y.bn_done:
@@ -791,6 +794,7 @@ class Plan(object):
         _, xin2, crec2, _, y2, bn2 = self.tape[ti - 1]
         _, xin1, crec1, _, y1, bn1 = self.tape[ti - 2]
         x = xin1.act
+        self.bwd.tags[len(self.bwd)] = crec2.prefix
         if not out.ginit:
             raise RuntimeError('no gradient reaches ' + out.name)
         assert not x.ginit and not y1.ginit and not y2.ginit

@@ -310,6 +310,39 @@ def test_batchnorm_backward_through_upsampled_sum(dtype, sh):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_grad_term_large_tensor_variant(dtype):
+    """tensors of >= 4 grid-stride steps per thread take grad_term_rows_kernel (per-channel coefficients kept
+    in registers): BatchNorm + ReLU backward apply on a head-sized 480-channel tensor, vs the formula"""
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cc = 18, 64, 64, 480
+    g = torch.Generator().manual_seed(17)
+    gr = _q(torch.randn(N, H, W, Cc, generator=g), dtype)
+    y = _q(torch.randn(N, H, W, Cc, generator=g), dtype)
+    mask = _q(torch.randn(N, H, W, Cc, generator=g), dtype)
+    prev = _q(torch.randn(N, H, W, Cc, generator=g), dtype)
+    sc, sf = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) - 0.5
+    coef = torch.cat([torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1])
+    dz = gr * (mask > 0) * ((y * sc + sf) > 0)
+    want = prev + coef[:Cc] * dz + coef[Cc:2 * Cc] * y + coef[2 * Cc:]
+    d = hh.DEV
+    dst = prev.to(dtype).to(d)
+    gd, yd, md = gr.to(dtype).to(d), y.to(dtype).to(d), mask.to(dtype).to(d)
+    scd, sfd, cd = sc.to(d), sf.to(d), coef.to(d)
+    C.call('hrnet_grad_term', hh.dt_id(dtype), dst.data_ptr(), gd.data_ptr(), md.data_ptr(), yd.data_ptr(), scd.data_ptr(),
+           sfd.data_ptr(), cd.data_ptr(), N, H, W, Cc, 0, 1, 1, C.stream_ptr())
+    assert hh.rel_err(dst.float().cpu(), want) <= (1e-5 if dtype == torch.float32 else 2e-2)
+    # the two-destination form (BatchNorm term + identity term of one residual sum)
+    dst1 = torch.empty_like(dst)
+    dst2 = prev.to(dtype).to(d)
+    C.call('hrnet_grad_term2', hh.dt_id(dtype), dst1.data_ptr(), dst2.data_ptr(), gd.data_ptr(), md.data_ptr(), yd.data_ptr(),
+           None, None, cd.data_ptr(), N, H, W, Cc, 0, 1, C.stream_ptr())
+    dz2 = gr * (mask > 0)
+    assert hh.rel_err(dst1.float().cpu(), coef[:Cc] * dz2 + coef[Cc:2 * Cc] * y + coef[2 * Cc:]) <= (1e-5 if dtype == torch.float32 else 2e-2)
+    assert hh.rel_err(dst2.float().cpu(), prev + dz2) <= (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('mode', ['bn_relu', 'bn_plain', 'sum_mask'])
 @pytest.mark.parametrize('case', [(2, 16, 16, 32, 32, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 8, 8, 256, 64, 1, 1),
                                   (2, 16, 16, 256, 64, 1, 1)])     # wide 1x1 output: its own tile choice
