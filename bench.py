@@ -254,6 +254,85 @@ def infer_main(args, model, x, world, rank, dev):
         dist.destroy_process_group()
 
 
+def dcn_main(args, world, rank, dev):
+    """config 5 (BASELINE.json): the deformable-convolution branch of pose_hrnet_PoseAggr at its geometry
+    (reference lib/models/pose_hrnet_PoseAggr.py:508-516,615-628): input (B,21,64,64), offsets (B,378,64,64),
+    weight (21,21,3,3), stride 1, dilation = padding = d for d in (3,6,12,18,24), 21 deformable groups.
+    One step = forward + backward (input, offset, weight gradients) of the five dilations on resident tensors.
+    HBM-bound: algorithmic bytes = offsets read once per pass + offset gradient written + input/output maps."""
+    from deformable_conv import DeformConvFunction
+    B = args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    cases = []
+    for dd in (3, 6, 12, 18, 24):
+        x = torch.randn(B, 21, 64, 64, device=dev, generator=g, requires_grad=True)
+        off = (torch.randn(B, 21 * 18, 64, 64, device=dev, generator=g) * 2).requires_grad_(True)
+        w = (torch.randn(21, 21, 3, 3, device=dev, generator=g) * 0.1).requires_grad_(True)
+        go = torch.randn(B, 21, 64, 64, device=dev, generator=g)
+        cases.append((dd, x, off, w, go))
+
+    def step():
+        for dd, x, off, w, go in cases:
+            x.grad = off.grad = w.grad = None
+            DeformConvFunction.apply(x, off, w, None, 1, dd, dd, 1, 21, 64).backward(go)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # per-pass kernel times on the launch stream (events), one dilation
+    dd, x, off, w, go = cases[2]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    n = 10
+    out = DeformConvFunction.apply(x, off, w, None, 1, dd, dd, 1, 21, 64)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(n):
+        out = DeformConvFunction.apply(x, off, w, None, 1, dd, dd, 1, 21, 64)
+    ev[1].record()
+    for _ in range(n):
+        out.backward(go, retain_graph=True)
+    ev[2].record()
+    torch.cuda.synchronize()
+    tf, tb = ev[0].elapsed_time(ev[1]) / n, ev[1].elapsed_time(ev[2]) / n
+    by_f = (off.numel() + x.numel() + out.numel()) * 4
+    by_b = (2 * off.numel() + 2 * x.numel() + out.numel()) * 4          # offsets read + offset gradient written
+    if rank == 0:
+        value = world * B * args.steps / dt
+        ach = by_b / (tb * 1e-3) / 1e9
+        print(json.dumps({
+            'metric': 'images/sec fwd+bwd DCNv1 branch of pose_hrnet_PoseAggr (5 dilations) 21ch 64x64 bs={}/GPU'.format(B),
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'deformable conv v1 forward+backward, input (B,21,64,64), offsets (B,378,64,64), 3x3, '
+                                   'dilations 3/6/12/18/24, 21 deformable groups, batch {}/GPU'.format(B),
+                       'global_batch': world * B, 'parallelism': 'replicas{}'.format(world)},
+            'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': round(ach / 8000.0, 4), 'traffic': None, 'kernel': 'dcn_bwd_fused_kernel (backward, dilation 12)',
+                         'avg_launch_us': round(tb * 1e3, 1), 'algorithmic_bytes_per_launch': by_b,
+                         'forward': {'achieved': round(by_f / (tf * 1e-3) / 1e9, 1), 'avg_launch_us': round(tf * 1e3, 1),
+                                     'algorithmic_bytes_per_launch': by_f}},
+            'cpu_baseline': None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -263,7 +342,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--arch', default='w32', choices=['w32', 'w48'],
                     help='w48 = BASELINE.json config 4: pose_hrnet_w48 384x288 (use --batch 32)')
-    ap.add_argument('--mode', default='train', choices=['train', 'infer'],
+    ap.add_argument('--mode', default='train', choices=['train', 'infer', 'dcn'],
                     help='train = the headline step (default); infer = BASELINE.json config 2: eval forward + '
                          'arg-max decode (use with --dtype fp32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -278,6 +357,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
+
+    if args.mode == 'dcn':
+        return dcn_main(args, world, rank, dev)
 
     from core.loss import HeatmapLoss
     from hipnet import synth

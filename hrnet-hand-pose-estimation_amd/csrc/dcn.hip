@@ -316,6 +316,122 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnArgs a) {
     }
 }
 
+// Single-pass backward for the PoseAggr geometry (one input channel per deformable group, one conv group,
+// Og <= 32, planes that fit LDS): a block owns (image b, channel c) and reads that channel's offsets ONCE for
+// all three gradients (the two-kernel path above streams the 396 MB of offsets twice and re-samples
+// everything for the weight gradient). Per step of 256 pixels:
+//   phase 1 (thread = pixel): g[o] of the pixel, then per tap gc = sum_o W[o,c,k] * g[o], the four bilinear
+//           corners from the input plane staged in LDS, the offset gradient stored directly, the scattered
+//           input gradient added into an LDS plane (ds_add_f32); the sample and g go to LDS rows;
+//   phase 2 (thread = (o,k) pair): dW[o,c,k] += sum over the 256 pixels of g[o,p] * sample[k,p] (16-byte LDS
+//           reads), so the weight-gradient sums cost a thread one register instead of Og*K.
+// The planes are stored coalesced at the end; one partial [Og][C][K] per image, summed over the images in
+// fixed order by dcn_weight_reduce_kernel (deterministic).
+template <int OGP, int KK>
+__global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int LD = 260;           // padded row of 256 pixels (16-byte aligned, rows 4 banks apart)
+  const int HW = a.H * a.W;
+  float* pl = sm;                   // [H*W] input plane
+  float* gpl = sm + HW;             // [H*W] input-gradient plane
+  float* wl = sm + 2 * HW;          // [KK][OGP] weights of this channel, zero beyond Og
+  float* gl = wl + KK * OGP;        // [OGP][LD] output gradients of the step's pixels
+  float* vl = gl + OGP * LD;        // [KK][LD] samples of the step's pixels
+  const int c = blockIdx.x, b = blockIdx.y;
+  for (int i = threadIdx.x; i < KK * OGP; i += 256) {
+    const int o = i % OGP, k = i / OGP;
+    wl[i] = o < a.Og ? a.w[((size_t)o * a.C + c) * KK + k] : 0.f;
+  }
+  const float* in_p = a.in + ((size_t)b * a.C + c) * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    pl[i] = in_p[i];
+    gpl[i] = 0.f;
+  }
+  const int plane_o = a.Ho * a.Wo;
+  const size_t obase0 = ((size_t)b * a.DG + c) * 2 * KK * plane_o;
+  const int po = threadIdx.x / KK, pk = threadIdx.x % KK;      // this thread's (o, k) pair in phase 2
+  const bool pair = threadIdx.x < a.Og * KK;
+  float dw = 0.f;
+  for (int p0 = 0; p0 < plane_o; p0 += 256) {
+    const int p = p0 + threadIdx.x;
+    const bool live = p < plane_o;
+    __syncthreads();          // staging done (first step) / phase 2 of the previous step has read gl, vl
+    if (live) {
+      const int y = p / a.Wo, x = p % a.Wo;
+      float g[OGP];
+#pragma unroll
+      for (int o = 0; o < OGP; ++o) g[o] = o < a.Og ? a.gout[((size_t)b * a.Co + o) * plane_o + p] : 0.f;
+      float oh[KK], ow[KK];     // all offsets of this pixel first (18 independent loads in flight)
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        oh[k] = a.off[obase0 + (size_t)(2 * k) * plane_o + p];
+        ow[k] = a.off[obase0 + (size_t)(2 * k + 1) * plane_o + p];
+      }
+#pragma unroll
+      for (int o = 0; o < OGP; ++o) gl[o * LD + threadIdx.x] = g[o];
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        const int i = k / a.kw, j = k % a.kw;
+        const float h = (float)(y * a.sh - a.ph + i * a.dh) + oh[k];
+        const float w = (float)(x * a.sw - a.pw + j * a.dw) + ow[k];
+        float gc = 0.f;
+        const float4* wk = reinterpret_cast<const float4*>(wl + k * OGP);
+#pragma unroll
+        for (int o = 0; o < OGP / 4; ++o) {
+          const float4 w4 = wk[o];
+          gc = fmaf(w4.x, g[4 * o], gc);
+          gc = fmaf(w4.y, g[4 * o + 1], gc);
+          gc = fmaf(w4.z, g[4 * o + 2], gc);
+          gc = fmaf(w4.w, g[4 * o + 3], gc);
+        }
+        float gh = 0.f, gw = 0.f, val = 0.f;
+        if (dcn_inside(h, w, a.H, a.W)) {
+          const int hl = (int)floorf(h), wl_ = (int)floorf(w);
+          const int hh_ = hl + 1, wh = wl_ + 1;
+          const float lh = h - hl, lw = w - wl_, hh = 1.f - lh, hw = 1.f - lw;
+          const bool ok1 = hl >= 0 && wl_ >= 0, ok2 = hl >= 0 && wh <= a.W - 1;
+          const bool ok3 = hh_ <= a.H - 1 && wl_ >= 0, ok4 = hh_ <= a.H - 1 && wh <= a.W - 1;
+          const float v1 = ok1 ? pl[hl * a.W + wl_] : 0.f, v2 = ok2 ? pl[hl * a.W + wh] : 0.f;
+          const float v3 = ok3 ? pl[hh_ * a.W + wl_] : 0.f, v4 = ok4 ? pl[hh_ * a.W + wh] : 0.f;
+          val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+          gh = gc * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+          gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
+          if (ok1) atomicAdd(gpl + hl * a.W + wl_, gc * hh * hw);
+          if (ok2) atomicAdd(gpl + hl * a.W + wh, gc * hh * lw);
+          if (ok3) atomicAdd(gpl + hh_ * a.W + wl_, gc * lh * hw);
+          if (ok4) atomicAdd(gpl + hh_ * a.W + wh, gc * lh * lw);
+        }
+        a.goff[obase0 + (size_t)(2 * k) * plane_o + p] = gh;
+        a.goff[obase0 + (size_t)(2 * k + 1) * plane_o + p] = gw;
+        vl[k * LD + threadIdx.x] = val;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < OGP; ++o) gl[o * LD + threadIdx.x] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KK; ++k) vl[k * LD + threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    if (pair) {
+      const float4* gr = reinterpret_cast<const float4*>(gl + po * LD);
+      const float4* vr = reinterpret_cast<const float4*>(vl + pk * LD);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 64; q += 2) {
+        const float4 g0 = gr[q], v0 = vr[q], g1 = gr[q + 1], v1 = vr[q + 1];
+        s0 = fmaf(g0.x, v0.x, s0); s0 = fmaf(g0.y, v0.y, s0); s0 = fmaf(g0.z, v0.z, s0); s0 = fmaf(g0.w, v0.w, s0);
+        s1 = fmaf(g1.x, v1.x, s1); s1 = fmaf(g1.y, v1.y, s1); s1 = fmaf(g1.z, v1.z, s1); s1 = fmaf(g1.w, v1.w, s1);
+      }
+      dw += s0 + s1;
+    }
+  }
+  __syncthreads();
+  float* out = a.gin + ((size_t)b * a.C + c) * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) out[i] = gpl[i];
+  // partial[b][o][c][k]: one [Og][C][K] block per image
+  if (pair) a.partial[(size_t)b * a.Og * a.C * KK + ((size_t)po * a.C + c) * KK + pk] = dw;
+}
+
 // one wave per weight element: lanes stride over the per-block partials, fixed-shape tree at the end
 __global__ __launch_bounds__(256) void dcn_weight_reduce_kernel(const float* partial, float* gw, int blocks,
                                                                 int n, int accumulate) {
@@ -422,6 +538,28 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
   const long long npix = (long long)B * Ho * Wo;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
   const int cpd = C / deformable_groups;
+  // single pass over the offsets for all three gradients (PoseAggr: 21 channels = 21 deformable groups, 3x3)
+  const int ogp = Og <= 24 ? 24 : 32;
+  const size_t lds_one = ((size_t)2 * H * W + (size_t)9 * ogp + (size_t)(ogp + 9) * 260) * 4;
+  // (scratch holds hrnet_deform_conv_wgrad_blocks() partials of [Og][C][K]; this path writes B of them)
+  if (groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 80 * 1024 && B <= 65535 &&
+      hrnet_deform_conv_wgrad_blocks(B, Ho, Wo) >= B) {
+    a.c0 = 0; a.Cg = Cg; a.o0 = 0; a.Og = Og;
+    if (ogp == 24) {
+      want_lds(dcn_bwd_fused_kernel<24, 9>, lds_one);
+      hipLaunchKernelGGL((dcn_bwd_fused_kernel<24, 9>), dim3(C, B), dim3(256), lds_one, s, a);
+    } else {
+      want_lds(dcn_bwd_fused_kernel<32, 9>, lds_one);
+      hipLaunchKernelGGL((dcn_bwd_fused_kernel<32, 9>), dim3(C, B), dim3(256), lds_one, s, a);
+    }
+    const int n = Og * Cg * K;
+    hipLaunchKernelGGL(dcn_weight_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)scratch, grad_weight,
+                       B, n, 0);
+    if (grad_bias)
+      hipLaunchKernelGGL(dcn_bias_grad_kernel, dim3(Co), dim3(256), 0, s, grad_output, grad_bias, B, Co,
+                         (long long)Ho * Wo, 0);
+    return hr_check_launch("deform_conv_backward");
+  }
   const size_t lds_fast = ((size_t)cpd * K * (Og <= 32 ? 32 : 64) + (size_t)cpd * H * W) * 4;
   const bool fast = Cg % cpd == 0 && lds_fast <= 64 * 1024;
   if (!fast) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
