@@ -547,6 +547,19 @@ class Plan(object):
         self.inter_gop = None
         in_region = False
         self._producer_sum = producer_sum
+        # Deferred weight gradients: the weight-gradient launches of the HighResolutionModules are off the critical
+        # path, and the end of the backward pass (transition1, layer1, the stem: one lane, a third of its wall
+        # time) leaves the other lanes idle - so they are recorded when their operands are final but ENQUEUED on
+        # the side lanes when the walk reaches that single-lane tail. Their gradients are complete only at the
+        # end of the program, so this is off under data parallelism (the bucketed exchange relies on gradients
+        # completing in reverse layer order); HRNET_DEFER_WGRAD=0 turns it off.
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not dp and not self.wlane
+                            and os.environ.get('HRNET_DEFER_WGRAD', '1') != '0')
+        self._deferred = []
+        self._deferred_lanes = []
+        self.n_deferred_wgrads = 0
+        first_fork = next((i for i, e in enumerate(self.tape) if e[0] == 'fork'), None)
         fused_at, fused_skip = self._find_fused_blocks(), set()
         self.n_fused_blocks = len(fused_at)
         for ti, (e, lane) in reversed(list(enumerate(zip(self.tape, self.tape_lanes)))):
@@ -568,6 +581,8 @@ class Plan(object):
                     self.bwd.fork(e[1])
                 else:
                     self.bwd.join(e[1])
+                    if self.defer_wgrad and ti == first_fork:
+                        self._emit_deferred_wgrads()
                     if self.wlane:
                         self.bwd.sync(self.wlane, 0)
                     # every gradient of this module (and of everything after it) is complete here
@@ -648,13 +663,17 @@ class Plan(object):
                     slabs = self._f32(nsplit * y.C * ks * ks * x.C)
                     self.slab_bytes += slabs.numel() * 4
                     wptrs[4] = C.ptr(slabs)
-                    self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
-                    self._wred.setdefault(self.bwd.lane, []).append(dict(
-                        slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
-                        ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
-                        accumulate=1))
-                    if lane == 0:
-                        self._wred_bytes += crec.Cout * crec.Cin * crec.ks * crec.ks * 4
+                    ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
+                               ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
+                               accumulate=1)
+                    if self.defer_wgrad and in_region and first_fork is not None and ti > first_fork:
+                        # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends
+                        self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
+                    else:
+                        self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
+                        self._wred.setdefault(self.bwd.lane, []).append(ent)
+                        if lane == 0:
+                            self._wred_bytes += crec.Cout * crec.Cin * crec.ks * crec.ks * 4
                 else:
                     self.max_slab = max(self.max_slab, nsplit * y.C * ks * ks * x.C)
                     i = self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
@@ -704,6 +723,8 @@ class Plan(object):
             for l in sorted(self._wred):
                 self._flush_wred(l)
             self.bwd.lane = 0
+            if self._deferred_lanes:
+                self.bwd.join(self._deferred_lanes)       # the deferred weight gradients (and their slab sums) are done
             self._upload_wred_tables()
 
     # ---- fused backward of a BasicBlock (conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU: pose_hrnet.py:41-57) ----
@@ -823,6 +844,25 @@ class Plan(object):
         x.ginit = x.gmasked = True
         if lane == 0 and not in_region:
             self._bucket_mark_after_conv(crec1)
+
+    def _emit_deferred_wgrads(self):
+        """enqueue the recorded weight-gradient launches on the side lanes (largest first, least-loaded lane)"""
+        side = [l for l in range(1, self.nlanes)]
+        if not self._deferred or not side:
+            return
+        keep = self.bwd.lane
+        self.bwd.lane = 0
+        self.bwd.fork(side)
+        load = {l: 0.0 for l in side}
+        for wints, wptrs, ent, cost in sorted(self._deferred, key=lambda d: -d[3]):
+            l = min(side, key=lambda q: load[q])
+            load[l] += cost
+            self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
+            self._wred.setdefault(l, []).append(ent)
+        self._deferred_lanes = side
+        self.n_deferred_wgrads = len(self._deferred)
+        self._deferred = []
+        self.bwd.lane = keep
 
     def _bucket_mark_after_conv(self, crec):
         if self.batch_wred:
