@@ -51,6 +51,7 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_PACK_TABLE: e = hr_launch_pack_table(op, s); break;
     case HR_OP_WGRAD_REDUCE_TABLE: e = hr_launch_wgrad_reduce_table(op, s); break;
     case HR_OP_BWD_FUSED: e = hr_launch_bwd_fused(op, s); break;
+    case HR_OP_BN_FINALIZE_TABLE: e = hr_launch_bn_finalize_table(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");
@@ -176,6 +177,35 @@ extern "C" int hrnet_sum_terms(int dtype, void* out, int N, int Ho, int Wo, int 
     op.p[9 + t] = shift ? (void*)shift[t] : nullptr;
   }
   return hr_launch_sum_terms(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_sum_terms_bnref(int dtype, void* out, int N, int Ho, int Wo, int C, int nterms,
+                                     const void* const* src, const float* const* scale, const float* const* shift,
+                                     const int* shifts, const int* relus, int relu_out, int sums_mode,
+                                     const float* inv_counts, float eps, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_SUM_TERMS);
+  HR_REQUIRE(nterms >= 1 && nterms <= 4 && src && shifts && relus && scale && shift && inv_counts, "sum_terms: args");
+  const int iv[7] = {dtype, N, Ho, Wo, C, nterms, relu_out};
+  memcpy(op.i, iv, sizeof(iv));
+  op.p[0] = out;
+  for (int t = 0; t < nterms; ++t) {
+    op.i[7 + t] = shifts[t];
+    op.i[11 + t] = relus[t];
+    op.p[1 + t] = (void*)src[t];
+    op.p[5 + t] = (void*)scale[t];
+    op.p[9 + t] = (void*)shift[t];
+    op.f[t] = inv_counts[t];
+  }
+  op.i[15] = sums_mode;
+  memcpy(&op.i[16], &eps, sizeof(float));
+  return hr_launch_sum_terms(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_bn_finalize_table(const HrBnEnt* table, int n, int total_blocks, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_BN_FINALIZE_TABLE);
+  op.i[0] = n; op.i[1] = total_blocks;
+  op.p[0] = (void*)table;
+  return hr_launch_bn_finalize_table(op, (hipStream_t)stream);
 }
 
 extern "C" int hrnet_grad_term(int dtype, void* dst, const void* g, const void* mask_out, const void* y,

@@ -107,6 +107,30 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
+// Batch statistics kept as 8 partial copies sums[8][2][C] (sum y, sum y^2): producers add their per-workgroup sums
+// with float atomics into copy (workgroup id & 7); consumers turn them into the BatchNorm affine on the fly, so
+// no finalize launch sits between a conv and the ops that read its output. The SAME function serves the
+// consumers and the batched finalize that fills the arrays the backward pass reads, so both see identical values.
+constexpr int HR_BN_COPIES = 8;
+__device__ __forceinline__ void hr_bn_from_sums(const float* sums, int C, int c, float inv_count, float eps,
+                                                float gamma, float beta, float& scale, float& shift, float& mean,
+                                                float& invstd, float& var_biased) {
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < HR_BN_COPIES; ++k) {
+    s1 += (double)sums[(k * 2 + 0) * C + c];
+    s2 += (double)sums[(k * 2 + 1) * C + c];
+  }
+  const double m = s1 * (double)inv_count;
+  double v = s2 * (double)inv_count - m * m;
+  if (v < 0.0) v = 0.0;
+  mean = (float)m;
+  var_biased = (float)v;
+  invstd = 1.0f / sqrtf(var_biased + eps);
+  scale = gamma * invstd;
+  shift = beta - mean * scale;
+}
+
 // host-side error plumbing (api.hip)
 void hr_set_error(const char* fmt, ...);
 int hr_check_launch(const char* what);
@@ -139,3 +163,4 @@ int hr_launch_fill(const HrOp& op, hipStream_t s);
 int hr_launch_pack_table(const HrOp& op, hipStream_t s);
 int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s);
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s);
+int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s);

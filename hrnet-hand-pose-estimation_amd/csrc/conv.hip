@@ -10,7 +10,7 @@ inline int conv_mode(const ConvArgs& a, bool in_relu) {
   if (a.bs_y) return CONV_BS;
   if (!a.bias && !a.upz && !a.accumulate && a.stats) return CONV_FWD;
   if (a.bias && !a.upz && !a.accumulate) return CONV_FWDB;
-  if (!a.bias && !a.in_scale && !in_relu && !a.stats) return CONV_DG;
+  if (!a.bias && !a.in_scale && !a.in_sums && !in_relu && !a.stats) return CONV_DG;
   return CONV_GENERIC;
 }
 }  // namespace
@@ -58,6 +58,15 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.bs_mask = (const char*)op.p[8];
   a.bs_scale = (const float*)op.p[9];
   a.bs_shift = (const float*)op.p[10];
+  a.in_sums = (const float*)op.p[11];
+  a.in_gamma = (const float*)op.p[12];
+  a.in_beta = (const float*)op.p[13];
+  a.in_inv_count = op.f[0];
+  a.in_eps = op.f[1];
+  a.stats_atomic = op.i[13];
+  HR_REQUIRE(!a.in_sums || (a.in_gamma && a.in_beta && !a.in_scale && Cin <= HR_CONV_MAXC && a.in_inv_count > 0.f),
+             "conv2d: input batch sums need gamma/beta, no scale/shift arrays, Cin <= %d", HR_CONV_MAXC);
+  HR_REQUIRE(!a.in_sums || !a.bs_y, "conv2d: batch-sum input is for forward launches");
   HR_REQUIRE(!a.bs_y || a.stats, "conv2d: backward statistics need a rows buffer");
   HR_REQUIRE(!a.bs_y || (!a.in_scale && !a.bias && !op.i[11]),
              "conv2d: backward statistics are for input-gradient launches (no input affine / ReLU / bias)");
@@ -111,6 +120,20 @@ extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float
   for (int k = 0; k < 13; ++k) op.i[k] = iv[k];
   op.p[0] = (void*)x; op.p[1] = (void*)w; op.p[2] = (void*)in_scale; op.p[3] = (void*)in_shift;
   op.p[4] = (void*)bias; op.p[5] = y; op.p[6] = stats;
+  return hr_launch_conv(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_conv2d_bnref(int dtype, const void* x, const void* w, const float* in_sums, const float* in_gamma,
+                                  const float* in_beta, float in_inv_count, float in_eps, const float* bias, void* y,
+                                  float* out_sums, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ks,
+                                  int stride, int in_relu, hr_stream_t stream) {
+  HrOp op = {};
+  op.kind = HR_OP_CONV;
+  const int iv[14] = {dtype, N, H, W, Cin, Ho, Wo, Cout, ks, stride, 0, in_relu, 0, 1};
+  for (int k = 0; k < 14; ++k) op.i[k] = iv[k];
+  op.p[0] = (void*)x; op.p[1] = (void*)w; op.p[4] = (void*)bias; op.p[5] = y; op.p[6] = out_sums;
+  op.p[11] = (void*)in_sums; op.p[12] = (void*)in_gamma; op.p[13] = (void*)in_beta;
+  op.f[0] = in_inv_count; op.f[1] = in_eps;
   return hr_launch_conv(op, (hipStream_t)stream);
 }
 

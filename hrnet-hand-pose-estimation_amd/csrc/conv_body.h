@@ -49,7 +49,17 @@ struct ConvArgs {
   int tiles_y, tiles_x, total_tiles, tpw;  // tpw = pixel tiles per workgroup
   int gx, gy;                              // pixel walks x output-channel blocks (1-D grid, see conv_body)
   int in_relu, upz, accumulate;
+  // input BatchNorm given as batch sums (hr_bn_from_sums) instead of scale/shift arrays: no finalize launch between
+  // the producer and this conv. stats_atomic: this launch's own statistics go to sums[8][2][Cout] by float atomics
+  // (zeroed by the caller) instead of one deterministic row per workgroup.
+  const float* in_sums;
+  const float* in_gamma;
+  const float* in_beta;
+  float in_inv_count, in_eps;
+  int stats_atomic;
 };
+
+constexpr int HR_CONV_MAXC = 768;   // channels of the on-the-fly coefficient table (w48 head: 720)
 
 template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
 struct ConvCfg {
@@ -78,7 +88,8 @@ struct ConvCfg {
   static constexpr int FC = CN / 16;   // cout fragments per wave
   static constexpr int LANE_C = 4 * FC;  // contiguous couts per lane
   static constexpr int STATB = WP * BN * 2 * (int)sizeof(float);
-  static constexpr int LDSB = (XBYTES + WBYTES) > STATB ? (XBYTES + WBYTES) : STATB;
+  static constexpr int LDSB0 = (XBYTES + WBYTES) > STATB ? (XBYTES + WBYTES) : STATB;
+  static constexpr int LDSB = (LDSB0 + 15) / 16 * 16;
   static_assert(WP * WC == 4, "4 waves");
   static_assert(PM % 16 == 0 && CN % 16 == 0, "fragment multiples");
   static_assert(256 % VPP == 0, "each thread keeps one channel vector");
@@ -109,9 +120,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   constexpr bool NO_STATS = MODE == CONV_DG;
   using C = ConvCfg<T, KS, STRIDE, TH, TW, BN, WP, WC, KM>;
   constexpr int VEC = C::VEC;
-  __shared__ __attribute__((aligned(16))) char lds[C::LDSB];
+  constexpr bool TAB = MODE == CONV_FWD || MODE == CONV_FWDB || MODE == CONV_GENERIC;   // modes that can read a BatchNorm'd input
+  __shared__ __attribute__((aligned(16))) char lds[C::LDSB + (TAB ? 2 * HR_CONV_MAXC * 4 : 0)];
   char* xl = lds;
   char* wl = lds + C::XBYTES;
+  float* bntab = (float*)(lds + C::LDSB);     // [scale Cin][shift Cin] computed from the producer's batch sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -144,7 +157,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   const bool wres = nch == 1;  // weights stay resident in LDS
   const int v = tid % C::VPP;  // this thread's 16-byte vector within a pixel / weight tap (fixed)
   // a backward-statistics launch is an input-gradient conv: raw dY in, no bias (checked by the launcher)
-  const bool has_affine = RAW_IN ? false : a.in_scale != nullptr;
+  const bool from_sums = TAB ? a.in_sums != nullptr : false;
+  const bool has_affine = RAW_IN ? false : (a.in_scale != nullptr || from_sums);
+  if constexpr (TAB) {
+    if (from_sums) {
+      for (int c = threadIdx.x; c < a.Cin; c += 256) {
+        float sc_, sh_, m_, r_, v_;
+        hr_bn_from_sums(a.in_sums, a.Cin, c, a.in_inv_count, a.in_eps, a.in_gamma[c], a.in_beta[c], sc_, sh_, m_, r_, v_);
+        bntab[c] = sc_;
+        bntab[a.Cin + c] = sh_;
+      }
+      __syncthreads();
+    }
+  }
   const bool in_relu = RAW_IN ? false : a.in_relu != 0;
   constexpr bool FWDLIKE = MODE == CONV_FWD || MODE == CONV_FWDB;
   const bool A_UPZ = FWDLIKE ? false : a.upz != 0;
@@ -237,10 +262,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
     if (has_affine && cvalid) {
+      if (from_sums) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        sc[j] = a.in_scale[c + j];
-        sh[j] = a.in_shift[c + j];
+        for (int j = 0; j < VEC; ++j) {
+          sc[j] = bntab[c + j];
+          sh[j] = bntab[a.Cin + c + j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          sc[j] = a.in_scale[c + j];
+          sh[j] = a.in_shift[c + j];
+        }
       }
     }
     xok = 0;
@@ -562,8 +595,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < WP; ++q) s += sl[(q * 2 + which) * BN + cl];
-      if (n0 + cl < a.Cout)
-        a.stats[((size_t)wg_p * 2 + which) * a.Cout + n0 + cl] = s;
+      if (n0 + cl < a.Cout) {
+        if (a.stats_atomic) atomicAdd(a.stats + ((size_t)(wg_p & (HR_BN_COPIES - 1)) * 2 + which) * a.Cout + n0 + cl, s);
+        else a.stats[((size_t)wg_p * 2 + which) * a.Cout + n0 + cl] = s;
+      }
     }
   }
 }

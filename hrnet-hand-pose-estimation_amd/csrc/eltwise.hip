@@ -98,11 +98,33 @@ struct SumArgs {
   int sh[4];
   int relu[4];
   int N, Ho, Wo, C, nterms, relu_out;
+  // bit t of sums_mode: term t's BatchNorm is given as batch sums (scale[t] = sums[8][2][C], shift[t] = gamma with
+  // beta = gamma + C) and turned into scale/shift per block (hr_bn_from_sums): no finalize launch before this op
+  int sums_mode;
+  float inv_count[4];
+  float eps;
 };
+
+constexpr int SUM_MAXC = 384;
 
 template <typename T>
 __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
   constexpr int VEC = TT<T>::VEC;
+  __shared__ float tab[4][2][SUM_MAXC];
+  if (a.sums_mode) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < a.nterms && ((a.sums_mode >> t) & 1)) {
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+          float sc_, sh_, m_, r_, v_;
+          hr_bn_from_sums(a.scale[t], a.C, c, a.inv_count[t], a.eps, a.shift[t][c], a.shift[t][a.C + c], sc_, sh_, m_, r_, v_);
+          tab[t][0][c] = sc_;
+          tab[t][1][c] = sh_;
+        }
+      }
+    }
+    __syncthreads();
+  }
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.Ho * a.Wo * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -125,7 +147,10 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
         const size_t off = ((size_t)((n * hs + (oy >> sh)) * ws + (ox >> sh)) * a.C + c) * sizeof(T);
         float f[VEC];
         v16_unpack<T>(*(const V16*)(a.src[t] + off), f);
-        if (a.scale[t]) {
+        if ((a.sums_mode >> t) & 1) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], tab[t][0][c + j], tab[t][1][c + j]);
+        } else if (a.scale[t]) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], a.scale[t][c + j], a.shift[t][c + j]);
         }
@@ -754,6 +779,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const HrWredEnt
                      (long long)((int)blockIdx.x - e.block0) * 64, red);
 }
 
+// every BatchNorm of a forward pass in ONE launch: batch sums -> the arrays the backward pass reads (scale, shift,
+// mean, invstd) and the running statistics (momentum update with the unbiased variance, num_batches_tracked).
+// Block b finds its entry by binary search (block0 = first block of an entry; 256 channels per block).
+__global__ __launch_bounds__(256) void bn_finalize_table_kernel(const HrBnEnt* tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const HrBnEnt e = tab[lo];
+  const int c = ((int)blockIdx.x - e.block0) * 256 + threadIdx.x;
+  if (c < e.C) {
+    float sc, sh, mean, invstd, var;
+    hr_bn_from_sums(e.sums, e.C, c, 1.0f / e.count, e.eps, e.gamma[c], e.beta[c], sc, sh, mean, invstd, var);
+    e.scale[c] = sc;
+    e.shift[c] = sh;
+    e.mean[c] = mean;
+    e.invstd[c] = invstd;
+    if (e.running_mean) {
+      const float unbiased = e.count > 1.f ? var * (e.count / (e.count - 1.f)) : var;
+      e.running_mean[c] = (1.f - e.momentum) * e.running_mean[c] + e.momentum * mean;
+      e.running_var[c] = (1.f - e.momentum) * e.running_var[c] + e.momentum * unbiased;
+    }
+  }
+  if (e.num_batches_tracked && (int)blockIdx.x == e.block0 && threadIdx.x == 0) *e.num_batches_tracked += 1;
+}
+
 __global__ __launch_bounds__(256) void fill_zero_kernel(V16* p, long long n16, char* tail, int ntail) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
        i += (long long)gridDim.x * blockDim.x)
@@ -787,6 +839,10 @@ int hr_launch_sum_terms(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(a.C % (dtype == HR_F32 ? 4 : 8) == 0, "sum_terms: C=%d", a.C);
   a.out = (char*)op.p[0];
   HR_REQUIRE(a.out, "sum_terms: null out");
+  a.sums_mode = op.i[15];
+  for (int t = 0; t < 4; ++t) a.inv_count[t] = op.f[t];
+  a.eps = __builtin_bit_cast(float, op.i[16]);
+  HR_REQUIRE(!a.sums_mode || a.C <= SUM_MAXC, "sum_terms: C=%d too wide for batch-sum terms", a.C);
   for (int t = 0; t < 4; ++t) {
     a.sh[t] = op.i[7 + t];
     a.relu[t] = op.i[11 + t];
@@ -1026,6 +1082,13 @@ int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(op.p[0] && n >= 1 && blocks >= 1, "wgrad_reduce_table: args");
   hipLaunchKernelGGL(wgrad_reduce_table_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const HrWredEnt*)op.p[0], n);
   return hr_check_launch("wgrad_reduce_table");
+}
+
+int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s) {
+  const int n = op.i[0], blocks = op.i[1];
+  HR_REQUIRE(op.p[0] && n >= 1 && blocks >= 1, "bn_finalize_table: args");
+  hipLaunchKernelGGL(bn_finalize_table_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const HrBnEnt*)op.p[0], n);
+  return hr_check_launch("bn_finalize_table");
 }
 
 int hr_launch_fill(const HrOp& op, hipStream_t s) {

@@ -22,7 +22,7 @@ class HrOp(ctypes.Structure):
                 ('p', ctypes.c_void_p * 14)]
 
 
-OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED = 17, 18, 19, 20, 21
+OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED, OP_BN_FINALIZE_TABLE = 17, 18, 19, 20, 21, 22
 LANE_SLOT = 18
 
 
@@ -39,6 +39,15 @@ class HrWredEnt(ctypes.Structure):
                 ('accumulate', ctypes.c_int32), ('block0', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class HrBnEnt(ctypes.Structure):
+    _fields_ = [('sums', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+                ('running_mean', ctypes.c_void_p), ('running_var', ctypes.c_void_p),
+                ('num_batches_tracked', ctypes.c_void_p), ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p),
+                ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p), ('count', ctypes.c_float),
+                ('momentum', ctypes.c_float), ('eps', ctypes.c_float), ('C', ctypes.c_int32), ('block0', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 _c_int, _c_float, _c_vp, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 _pp = ctypes.POINTER(ctypes.c_void_p)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -51,6 +60,9 @@ _SIGS = {
     'hrnet_event_destroy': [_c_vp],
     'hrnet_conv2d': [_c_int] + [_c_vp] * 7 + [_c_int] * 12 + [_c_vp],
     'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
+    'hrnet_conv2d_bnref': [_c_int] + [_c_vp] * 5 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 10 + [_c_vp],
+    'hrnet_bn_finalize_table': [_c_vp, _c_int, _c_int, _c_vp],
+    'hrnet_sum_terms_bnref': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_int, ctypes.POINTER(ctypes.c_float), _c_float, _c_vp],
     'hrnet_conv_mode': [_c_int] * 7,
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_tiles_bwdstats': [_c_int] * 6,

@@ -81,6 +81,8 @@ class BNRec(object):
         self.mean = torch.empty(c, **f)
         self.invstd = torch.empty(c, **f)
         self.coef = torch.empty(3 * c, **f)
+        self.sums = None        # [8][2][C] batch sums (consumer-side BatchNorm; a slice of the plan's arena)
+        self.count = 0.0        # elements per channel the sums cover
 
 
 class ConvRec(object):
@@ -272,21 +274,31 @@ class Plan(object):
         want_stats = bnrec is not None and self.training
         tiles = C.call('hrnet_conv_tiles', x.N, Ho, Wo, crec.Cout_pad, ks, stride)
         bias = crec.mod.bias
+        sums_in = self.bn_sums and xin.bn is not None       # the input's BatchNorm from its batch sums, on the fly
+        m_in = xin.bn.mod if xin.bn is not None else None
         i = self.fwd.add(C.OP_CONV,
                          ints=(self.dtid, x.N, x.H, x.W, cin, Ho, Wo, crec.Cout_pad, ks, stride, 0,
-                               1 if xin.relu else 0, 0),
-                         ptrs=(C.ptr(x.t), C.ptr(crec.wf), C.ptr(xin.bn.scale) if xin.bn else None,
-                               C.ptr(xin.bn.shift) if xin.bn else None,
+                               1 if xin.relu else 0, 0, 1 if (want_stats and self.bn_sums) else 0),
+                         floats=((1.0 / xin.bn.count, m_in.eps) if sums_in else ()),
+                         ptrs=(C.ptr(x.t), C.ptr(crec.wf),
+                               C.ptr(xin.bn.scale) if (xin.bn and not sums_in) else None,
+                               C.ptr(xin.bn.shift) if (xin.bn and not sums_in) else None,
                                C.ptr(self.net.bias_pad[crec.prefix]) if bias is not None else None,
-                               C.ptr(y.t), None))
+                               C.ptr(y.t), C.ptr(bnrec.sums) if (want_stats and self.bn_sums) else None,
+                               None, None, None, None,
+                               C.ptr(xin.bn.sums) if sums_in else None, C.ptr(m_in.weight) if sums_in else None,
+                               C.ptr(m_in.bias) if sums_in else None))
         self.fwd.tags[i] = crec.prefix
-        if want_stats:
+        if want_stats and not self.bn_sums:
             self.max_stats = max(self.max_stats, tiles * 2 * crec.Cout_pad)
             self._scratch(self.fwd, i, 6, 'stats')
         x.nuse += 1
         if bnrec is not None:
             y.bn = bnrec
-            if self.training:
+            bnrec.count = float(y.pixels)
+            if self.training and self.bn_sums:
+                self.bn_finalize_list.append(bnrec)      # one table-driven launch at the end of the pass
+            elif self.training:
                 m = bnrec.mod
                 j = self.fwd.add(C.OP_BN_FINALIZE, ints=(tiles, bnrec.C, 1),
                                  floats=(y.pixels, m.momentum if m.momentum is not None else 0.1, m.eps),
@@ -306,9 +318,18 @@ class Plan(object):
         ints += [1 if t.relu else 0 for t in terms] + [0] * (4 - len(terms))
         ptrs = [C.ptr(out.t)]
         ptrs += [C.ptr(t.act.t) for t in terms] + [None] * (4 - len(terms))
-        ptrs += [C.ptr(t.bn.scale) if t.bn else None for t in terms] + [None] * (4 - len(terms))
-        ptrs += [C.ptr(t.bn.shift) if t.bn else None for t in terms] + [None] * (4 - len(terms))
-        self.fwd.add(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
+        if self.bn_sums and any(t.bn for t in terms):
+            import struct
+            mode = sum(1 << k for k, t in enumerate(terms) if t.bn)
+            ints += [mode, struct.unpack('i', struct.pack('f', float(next(t.bn.mod.eps for t in terms if t.bn))))[0]]
+            ptrs += [C.ptr(t.bn.sums) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+            ptrs += [C.ptr(t.bn.mod.weight) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+            floats = [1.0 / t.bn.count if t.bn else 0.0 for t in terms] + [0.0] * (4 - len(terms))
+            self.fwd.add(C.OP_SUM_TERMS, ints=ints, floats=floats, ptrs=ptrs)
+        else:
+            ptrs += [C.ptr(t.bn.scale) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+            ptrs += [C.ptr(t.bn.shift) if t.bn else None for t in terms] + [None] * (4 - len(terms))
+            self.fwd.add(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
         for t in terms:
             t.act.nuse += 1
         self._tape(('sum', list(terms), list(shifts), relu_out, out))
@@ -336,6 +357,24 @@ class Plan(object):
         # BatchNorm coefficient buffers (scale/shift/mean/invstd/coef) belong to the PLAN: two plans of one net
         # can be in flight at once (hipnet.net.HipNet.plan), and each backward needs its own forward's statistics
         self.bns = {name: BNRec(name, rec.mod, self.dev) for name, rec in net.bns.items()}
+        # Consumer-side BatchNorm (training): producers add their batch sums into 8 partial copies per BatchNorm with
+        # float atomics, forward consumers build scale/shift from them on the fly, and ONE table-driven launch at the
+        # end of the pass fills the arrays the backward pass reads and updates the running statistics - instead of a
+        # finalize launch after each of the 306 convs. HRNET_DETERMINISTIC=1: per-workgroup rows + a finalize launch
+        # per BatchNorm (bit-reproducible statistics).
+        contiguous = all(b.mod.bias.data_ptr() == b.mod.weight.data_ptr() + 4 * b.C for b in self.bns.values())
+        self.bn_sums = (self.training and contiguous and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
+                        and max(b.C for b in self.bns.values()) <= 768)
+        self.bn_finalize_list = []
+        if self.bn_sums:
+            total = sum(16 * b.C for b in self.bns.values())
+            self.bn_arena = self._f32(total, zero=True)
+            off = 0
+            for b in self.bns.values():
+                b.sums = self.bn_arena[off:off + 16 * b.C]
+                off += 16 * b.C
+            nbytes = total * 4
+            self.fwd.add(C.OP_FILL, ints=(nbytes & 0xffffffff, nbytes >> 32), ptrs=(C.ptr(self.bn_arena),))
         cv, bn = net.convs, self.bns
         if not self.training:
             for b in self.bns.values():
@@ -395,6 +434,8 @@ class Plan(object):
         self.inter_op = self.fwd.add(C.OP_NHWC_TO_NCHW,
                                      ints=(self.dtid, N, inter.act.H, inter.act.W, inter.act.C, inter.act.C),
                                      ptrs=(C.ptr(inter.act.t), None))
+        if self.bn_sums and self.bn_finalize_list:
+            self._add_bn_finalize_table()
         if self.need_grad:
             self._build_backward()
             if self.wlane:
@@ -402,6 +443,24 @@ class Plan(object):
         self._resolve_scratch()
         self.fwd.finalize()
         self.bwd.finalize()
+
+    def _add_bn_finalize_table(self):
+        ents = (C.HrBnEnt * len(self.bn_finalize_list))()
+        block = 0
+        for e, b in zip(ents, self.bn_finalize_list):
+            m = b.mod
+            e.sums, e.gamma, e.beta = C.ptr(b.sums), C.ptr(m.weight), C.ptr(m.bias)
+            e.running_mean, e.running_var = C.ptr(m.running_mean), C.ptr(m.running_var)
+            e.num_batches_tracked = C.ptr(m.num_batches_tracked)
+            e.scale, e.shift, e.mean, e.invstd = C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.mean), C.ptr(b.invstd)
+            e.count, e.momentum, e.eps = b.count, (m.momentum if m.momentum is not None else 0.1), m.eps
+            e.C, e.block0 = b.C, block
+            block += (b.C + 255) // 256
+        raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+        self.keep.append(table)
+        self.fwd.lane = 0
+        self.fwd.add(C.OP_BN_FINALIZE_TABLE, ints=(len(self.bn_finalize_list), block), ptrs=(C.ptr(table),))
 
     def _hr_module(self, xs, pre, num_blocks):
         """HighResolutionModule.forward, pose_hrnet.py:247-266."""

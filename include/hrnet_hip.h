@@ -61,7 +61,8 @@ enum {
   HR_OP_EVENT_RECORD = 18, /* p[0] = event, recorded on the op's lane */
   HR_OP_STREAM_WAIT = 19,  /* p[0] = event, the op's lane waits for it */
   HR_OP_WGRAD_REDUCE_TABLE = 20, /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
-  HR_OP_BWD_FUSED = 21     /* hrnet_conv3x3_bwd_fused */
+  HR_OP_BWD_FUSED = 21,    /* hrnet_conv3x3_bwd_fused */
+  HR_OP_BN_FINALIZE_TABLE = 22 /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -222,6 +223,43 @@ int hrnet_bn_finalize(const float* stats, int tiles, int C, float count, const f
                       int64_t* num_batches_tracked, float momentum, float eps, int training,
                       float* scale, float* shift, float* save_mean, float* save_invstd,
                       hr_stream_t stream);
+
+/*
+ * Consumer-side BatchNorm: instead of a finalize launch after every conv, a producer accumulates its batch sums
+ * into sums[8][2][C] with float atomics (hrnet_conv2d_bnref: out_sums, zeroed by the caller before the pass) and
+ * every forward consumer turns sums + gamma/beta into scale/shift itself (one table per workgroup). ONE
+ * hrnet_bn_finalize_table launch at the end of the pass fills, for every BatchNorm of the table, the arrays the
+ * backward pass reads (scale, shift, save_mean, save_invstd) and updates the running statistics - with the same
+ * arithmetic, so both passes see identical coefficients. Atomic accumulation makes the last bits of the batch
+ * statistics run-to-run dependent (like cuDNN's); hrnet_conv2d + hrnet_bn_finalize remain the deterministic form.
+ *   hrnet_conv2d_bnref: hrnet_conv2d with the input affine given as (in_sums, in_gamma, in_beta, 1/count, eps)
+ *   (NULL in_sums: no input BatchNorm) and the output statistics added into out_sums (NULL: none).
+ */
+int hrnet_conv2d_bnref(int dtype, const void* x, const void* w, const float* in_sums, const float* in_gamma,
+                       const float* in_beta, float in_inv_count, float in_eps, const float* bias, void* y,
+                       float* out_sums, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride,
+                       int in_relu, hr_stream_t stream);
+typedef struct HrBnEnt {
+  const float* sums;   /* [8][2][C] */
+  const float* gamma;
+  const float* beta;
+  float* running_mean; /* may be NULL */
+  float* running_var;
+  int64_t* num_batches_tracked; /* may be NULL */
+  float* scale;
+  float* shift;
+  float* mean;
+  float* invstd;
+  float count, momentum, eps;
+  int32_t C, block0, reserved;
+} HrBnEnt;
+/* `table`: DEVICE array of n entries; entry e covers blocks [block0, block0 + ceil(C/256)); total_blocks = sum */
+int hrnet_bn_finalize_table(const HrBnEnt* table, int n, int total_blocks, hr_stream_t stream);
+/* hrnet_sum_terms with BatchNorm terms given as batch sums: bit t of sums_mode set -> scale[t] = sums[8][2][C],
+ * shift[t] = gamma (beta = gamma + C), inv_counts[t] = 1 / (elements per channel of term t) */
+int hrnet_sum_terms_bnref(int dtype, void* out, int N, int Ho, int Wo, int C, int nterms, const void* const* src,
+                          const float* const* scale, const float* const* shift, const int* shifts, const int* relus,
+                          int relu_out, int sums_mode, const float* inv_counts, float eps, hr_stream_t stream);
 
 /*
  * out[N,Ho,Wo,C] = relu_out( sum_{t<nterms} relu_t( src_t[nearest-up by 2^sh_t] * scale_t + shift_t ) )

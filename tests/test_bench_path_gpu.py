@@ -344,6 +344,13 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
                 continue
             prog32.run(k, k + 1)
             prog16.run(k, k + 1)
+            if int(o32.kind) == C.OP_BN_FINALIZE_TABLE:
+                # the arrays the backward pass reads (scale, shift, mean, invstd of every BatchNorm): exact values
+                for name, b32 in p32.bns.items():
+                    b16 = p16.bns[name]
+                    for t32, t16 in ((b32.scale, b16.scale), (b32.shift, b16.shift), (b32.mean, b16.mean), (b32.invstd, b16.invstd)):
+                        t16.copy_(t32)
+                continue
             for (q32, is_act), (q16, _) in zip(_written(o32, C), _written(o16, C)):
                 if is_act:
                     if q32 not in a32:
@@ -408,7 +415,7 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
     ge_w = report(ge_w, 'conv weight gradients')
     ge_b = report(ge_b, 'BatchNorm / bias gradients (per-channel sums)')
     assert (hm16 - hm32).norm().item() <= 1e-2 * hm32.norm().item()
-    assert len(fe) >= 600 and len(be) >= (900 if fused == 'unfused' else 700) and len(ge_w) >= 300
+    assert len(fe) >= 400 and len(be) >= (900 if fused == 'unfused' else 700) and len(ge_w) >= 300
     # bf16 operands (2^-9 relative rounding of inputs, weights and the stored result), f32 accumulation.
     # Measured (MI355X): forward median 1.6e-3 / worst 4.3e-3; backward median 2.4e-3; conv weight gradients
     # p99 4.4e-3; per-channel sums up to 5e-2 where the sum cancels (see above).
@@ -430,6 +437,7 @@ def test_fused_backward_matches_unfused_backward(dtype, monkeypatch):
     parameter gradient is compared tightly. bf16 covers both fused instantiations (32 and 64 channels)."""
     from hipnet import synth
     batch = synth.rhd_batch(4, seed=31, img_h=128, img_w=128)
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1')     # bit-reproducible batch statistics: the two forward passes agree exactly
     monkeypatch.setenv('HRNET_FUSED_BWD', '0')
     mu, sd = _model(dtype, init='reference', salt=6)
     hm_u, _, loss_u, gu = _hip_step(mu, batch)

@@ -19,6 +19,7 @@ def _worker(rank, world, port, q):
     try:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
+        os.environ['HRNET_DETERMINISTIC'] = '1'      # the test compares two runs bit for bit
         for p in (REPO, os.path.join(PKG, 'lib')):
             if p not in sys.path:
                 sys.path.insert(0, p)

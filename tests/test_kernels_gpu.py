@@ -240,6 +240,85 @@ def test_bn_finalize_train_and_eval(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_consumer_side_batchnorm_conv_sum_and_table_finalize(dtype):
+    """hrnet_conv2d_bnref / hrnet_sum_terms_bnref / hrnet_bn_finalize_table: a conv accumulates its batch sums with
+    float atomics; the next conv and a residual sum read that output through BatchNorm(+ReLU) built on the fly from
+    the sums; one table launch produces scale/shift/mean/invstd + running statistics. Reference: torch BatchNorm2d
+    in training mode (pose_hrnet.py:41-57 conv-bn-relu-conv / bn + residual)."""
+    import ctypes
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, C1, C2 = 40, 64, 64, 32, 32        # 640 pixel tiles: the multi-tile walk, 320 workgroups adding into 8 copies
+    g = torch.Generator().manual_seed(23)
+    x = _q(torch.randn(N, C1, H, W, generator=g), dtype)
+    w1 = _q(torch.randn(C2, C1, 3, 3, generator=g) / 17.0, dtype)
+    w2 = _q(torch.randn(C2, C2, 3, 3, generator=g) / 17.0, dtype)
+    bn = torch.nn.BatchNorm2d(C2)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C2, generator=g) + 0.5)
+        bn.bias.copy_(torch.rand(C2, generator=g) - 0.5)
+    bn.train()
+    y1 = F.conv2d(x, w1, None, padding=1)
+    a1 = _q(F.relu(bn(_q(y1, dtype))).detach(), dtype)
+    y2 = F.conv2d(a1, w2, None, padding=1)
+    res = F.relu(F.batch_norm(_q(y1, dtype), None, None, bn.weight, bn.bias, True) + x)   # relu(bn(y1) + x)
+    d = hh.DEV
+    wp1, _, _ = hh.pack_weights(w1, dtype)
+    wp2, _, _ = hh.pack_weights(w2, dtype)
+    xd = hh.nhwc(x, dtype)
+    sums1 = torch.zeros(8, 2, C2, device=d)
+    sums2 = torch.zeros(8, 2, C2, device=d)
+    y1d = torch.empty(N, H, W, C2, dtype=dtype, device=d)
+    y2d = torch.empty(N, H, W, C2, dtype=dtype, device=d)
+    gam, bet = bn.weight.detach().to(d), bn.bias.detach().to(d)
+    cnt = float(N * H * W)
+    C.call('hrnet_conv2d_bnref', hh.dt_id(dtype), xd.data_ptr(), wp1.data_ptr(), None, None, None, 0.0, 0.0, None,
+           y1d.data_ptr(), sums1.data_ptr(), N, H, W, C1, H, W, C2, 3, 1, 0, C.stream_ptr())
+    assert hh.rel_err(hh.from_nhwc(y1d), y1) <= TOL[dtype]
+    s = sums1.double().sum(0).cpu()
+    assert hh.rel_err(s[1], (y1.double() ** 2).sum((0, 2, 3))) <= 5 * TOL[dtype]
+    # consumer conv: relu(bn(y1)) built from the sums on the fly
+    C.call('hrnet_conv2d_bnref', hh.dt_id(dtype), y1d.data_ptr(), wp2.data_ptr(), sums1.data_ptr(), gam.data_ptr(),
+           bet.data_ptr(), 1.0 / cnt, 1e-5, None, y2d.data_ptr(), sums2.data_ptr(), N, H, W, C2, H, W, C2, 3, 1, 1,
+           C.stream_ptr())
+    assert hh.rel_err(hh.from_nhwc(y2d), y2) <= 2 * TOL[dtype] + (0 if dtype == torch.float32 else 1e-2)
+    # consumer sum: relu(bn(y1) + x)
+    out = torch.empty(N, H, W, C2, dtype=dtype, device=d)
+    srcs = [y1d, xd]
+    inv = (ctypes.c_float * 4)(1.0 / cnt, 0.0, 0.0, 0.0)
+    gb = torch.cat([gam, bet])                      # gamma with beta = gamma + C, as the flat parameter buffer holds them
+    C.call('hrnet_sum_terms_bnref', hh.dt_id(dtype), out.data_ptr(), N, H, W, C2, 2, hh.ptr_array(srcs),
+           hh.ptr_array([sums1, None]), hh.ptr_array([gb, None]), hh.int_array([0, 0]), hh.int_array([0, 0]), 1, 1,
+           inv, 1e-5, C.stream_ptr())
+    assert hh.rel_err(hh.from_nhwc(out), res.detach()) <= 2 * TOL[dtype]
+    # table finalize: arrays for the backward pass + running statistics
+    rm, rv = torch.zeros(C2, device=d), torch.ones(C2, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    scale, shift, mean, invstd = (torch.empty(C2, device=d) for _ in range(4))
+    ent = (C.HrBnEnt * 1)()
+    e = ent[0]
+    e.sums, e.gamma, e.beta = sums1.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    e.running_mean, e.running_var, e.num_batches_tracked = rm.data_ptr(), rv.data_ptr(), nbt.data_ptr()
+    e.scale, e.shift, e.mean, e.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    e.count, e.momentum, e.eps, e.C, e.block0 = cnt, 0.1, 1e-5, C2, 0
+    raw = bytes(ctypes.string_at(ctypes.addressof(ent), ctypes.sizeof(ent)))
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(d)
+    C.call('hrnet_bn_finalize_table', table.data_ptr(), 1, 1, C.stream_ptr())
+    ref_bn = torch.nn.BatchNorm2d(C2)
+    ref_bn.train()
+    ref_bn(y1)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(rm.cpu().numpy(), ref_bn.running_mean.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(rv.cpu().numpy(), ref_bn.running_var.numpy(), rtol=tol, atol=tol)
+    assert int(nbt.item()) == 1
+    m = y1.mean((0, 2, 3))
+    r = 1.0 / torch.sqrt(y1.var((0, 2, 3), unbiased=False) + 1e-5)
+    np.testing.assert_allclose(mean.cpu().numpy(), m.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(invstd.cpu().numpy(), r.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(scale.cpu().numpy(), (bn.weight.detach() * r).numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_sum_terms_fuse_with_nearest_upsampling(dtype):
     hh = _h()
     from hipnet import _capi as C

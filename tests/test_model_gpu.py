@@ -193,7 +193,8 @@ def test_train_b4_matches_reference_golden(golden_dir):
             np.testing.assert_allclose(msd[k[5:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
 
 
-def test_gradient_accumulation_and_zero_grad_semantics():
+def test_gradient_accumulation_and_zero_grad_semantics(monkeypatch):
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1')     # compares gradients of repeated runs
     from hipnet import synth
     from core.loss import HeatmapLoss
     model, _, _ = make_model('fp32', 2)
@@ -212,9 +213,10 @@ def test_gradient_accumulation_and_zero_grad_semantics():
     assert torch.allclose(p.grad, g1, rtol=1e-5, atol=1e-7)
 
 
-def test_two_forwards_before_their_backwards_keep_separate_activations():
+def test_two_forwards_before_their_backwards_keep_separate_activations(monkeypatch):
     """a plan owns its activation buffers: a second training forward of the same shape before the first one's
     backward (summed micro-batch losses, siamese / consistency losses) must not overwrite what that backward reads"""
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1')     # compares gradients of repeated runs
     from hipnet import synth
     from core.loss import HeatmapLoss
     model, _, _ = make_model('fp32', 2)
@@ -247,6 +249,38 @@ def test_two_forwards_before_their_backwards_keep_separate_activations():
     l4.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match='activations of this forward pass are gone'):
         l4.backward()
+
+
+def test_atomic_batch_statistics_agree_with_the_deterministic_form(monkeypatch):
+    """default training mode (consumer-side BatchNorm: batch sums by float atomics, no finalize launches) against
+    HRNET_DETERMINISTIC=1 (per-workgroup rows + a finalize launch per BatchNorm): same network, same batch.
+    The sums differ in their last bits only; this random-init stack amplifies that, so the
+    comparison is on the forward pass and the running statistics, fp32 device path."""
+    from hipnet import synth
+    b = synth.rhd_batch(4, seed=11, img_h=128, img_w=128)
+    x = torch.from_numpy(b['imgs']).cuda()
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('HRNET_DETERMINISTIC', mode)
+        model, _, _ = make_model('fp32', 5)
+        model.train()
+        with torch.no_grad():
+            hm, inter = model(x)
+        plan = model.hip().all_plans()[0]
+        assert plan.bn_sums == (mode == '0')
+        from hipnet import _capi as C
+        n_fin = sum(1 for o in plan.fwd.ops if int(o.kind) == C.OP_BN_FINALIZE)
+        assert n_fin == (0 if mode == '0' else 306)
+        sd = model.state_dict()
+        out[mode] = (hm.cpu(), inter.cpu(), {k: v.cpu().clone() for k, v in sd.items() if 'running' in k or 'num_batches' in k})
+    a, d = out['0'], out['1']
+    assert (a[0] - d[0]).abs().max().item() <= 1e-3 * max(1.0, d[0].abs().max().item())
+    assert (a[1] - d[1]).abs().max().item() <= 1e-3 * max(1.0, d[1].abs().max().item())
+    for k, v in d[2].items():
+        if v.dtype == torch.int64:
+            assert int(a[2][k]) == int(v) == 1
+        else:
+            np.testing.assert_allclose(a[2][k].numpy(), v.numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
 
 
 def test_optimizer_step_changes_output_and_inter_feat_gradient_path():
