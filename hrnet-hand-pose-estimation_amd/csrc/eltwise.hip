@@ -479,13 +479,36 @@ __global__ __launch_bounds__(256) void bilinear_cat_kernel(CatArgs a) {
 
 // gather form of the transpose: one thread per (branch pixel, channel vector); loops over the
 // destination pixels whose bilinear footprint touches it and re-evaluates the forward weights.
+// The destination window of a source pixel is at most 2*ceil(out/in) + 1 wide; the x weights of the window are
+// evaluated once per thread into registers (CATB_MAXW entries, statically indexed) and reused for every row, so
+// the inner loop is one 16-byte load + VEC fmas per touched pixel with the row's loads issued together.
+constexpr int CATB_MAXW = 20;
+
+__device__ __forceinline__ void bilin_window(int s, int in_size, int out_size, int align, int& d0, int& d1) {
+  // destinations whose source coordinate lies in (s-1, s+1), padded by one on both sides (weights that turn out
+  // zero are skipped); the clamped ends of the axis extend to the border
+  float lo, hi;
+  if (align) {
+    const float inv = in_size > 1 ? (float)(out_size - 1) / (float)(in_size - 1) : 0.f;
+    lo = (float)(s - 1) * inv;
+    hi = (float)(s + 1) * inv;
+  } else {
+    const float f = (float)out_size / (float)in_size;
+    lo = ((float)s - 0.5f) * f - 0.5f;
+    hi = ((float)s + 1.5f) * f - 0.5f;
+  }
+  d0 = (int)floorf(lo) - 1;
+  d1 = (int)ceilf(hi) + 2;
+  if (d0 < 0 || s == 0) d0 = 0;
+  if (d1 > out_size || s == in_size - 1) d1 = out_size;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_cat_bwd_kernel(CatArgs a, int b) {
   constexpr int VEC = TT<T>::VEC;
   const int hs = a.hs[b], ws = a.ws[b], cs = a.cs[b];
   const int cv = cs / VEC;
   const long long total = (long long)a.N * hs * ws * cv;
-  const int fy = (a.H + hs - 1) / hs, fx = (a.W + ws - 1) / ws;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(idx % cv);
@@ -501,29 +524,37 @@ __global__ __launch_bounds__(256) void bilinear_cat_bwd_kernel(CatArgs a, int b)
     if (hs == a.H && ws == a.W) {
       v16_unpack<T>(*(const V16*)(a.cat + ((size_t)((n * a.H + sy) * a.W + sx) * a.Ctot + a.coff[b] + c) * sizeof(T)), o);
     } else {
-      int dy0 = (sy - 1) * fy - 1, dy1 = (sy + 2) * fy + 1;
-      int dx0 = (sx - 1) * fx - 1, dx1 = (sx + 2) * fx + 1;
-      if (dy0 < 0) dy0 = 0;
-      if (dx0 < 0) dx0 = 0;
-      if (dy1 > a.H) dy1 = a.H;
-      if (dx1 > a.W) dx1 = a.W;
-      for (int dy = dy0; dy < dy1; ++dy) {
-        int y0, y1;
-        float ly;
-        bilin_src(dy, hs, a.H, a.align, y0, y1, ly);
-        const float wy = (y0 == sy ? 1.f - ly : 0.f) + (y1 == sy ? ly : 0.f);
-        if (wy == 0.f) continue;
-        for (int dx = dx0; dx < dx1; ++dx) {
+      int dy0, dy1, dx0, dx1;
+      bilin_window(sy, hs, a.H, a.align, dy0, dy1);
+      bilin_window(sx, ws, a.W, a.align, dx0, dx1);
+      for (int dxb = dx0; dxb < dx1; dxb += CATB_MAXW) {      // (one pass unless the factor exceeds 8)
+        float wxs[CATB_MAXW];
+#pragma unroll
+        for (int j = 0; j < CATB_MAXW; ++j) {
+          const int dx = dxb + j;
           int x0, x1;
           float lx;
-          bilin_src(dx, ws, a.W, a.align, x0, x1, lx);
+          bilin_src(dx < a.W ? dx : a.W - 1, ws, a.W, a.align, x0, x1, lx);
           const float wx = (x0 == sx ? 1.f - lx : 0.f) + (x1 == sx ? lx : 0.f);
-          if (wx == 0.f) continue;
-          float gv[VEC];
-          v16_unpack<T>(*(const V16*)(a.cat + ((size_t)((n * a.H + dy) * a.W + dx) * a.Ctot + a.coff[b] + c) * sizeof(T)), gv);
-          const float w = wy * wx;
+          wxs[j] = dx < dx1 ? wx : 0.f;
+        }
+        for (int dy = dy0; dy < dy1; ++dy) {
+          int y0, y1;
+          float ly;
+          bilin_src(dy, hs, a.H, a.align, y0, y1, ly);
+          const float wy = (y0 == sy ? 1.f - ly : 0.f) + (y1 == sy ? ly : 0.f);
+          if (wy == 0.f) continue;
+          const char* row = a.cat + ((size_t)((n * a.H + dy) * a.W + dxb) * a.Ctot + a.coff[b] + c) * sizeof(T);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) o[j] = fmaf(w, gv[j], o[j]);
+          for (int j = 0; j < CATB_MAXW; ++j) {
+            if (wxs[j] != 0.f) {
+              float gv[VEC];
+              v16_unpack<T>(*(const V16*)(row + (size_t)j * a.Ctot * sizeof(T)), gv);
+              const float w = wy * wxs[j];
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) o[k] = fmaf(w, gv[k], o[k]);
+            }
+          }
         }
       }
     }
@@ -722,14 +753,61 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* parti
   }
 }
 
-// one 64-element chunk x 4 slab lanes: each lane sums its slabs with 4 loads in flight, LDS adds the
-// lanes in a fixed order (deterministic). idx enumerates the slab order (co, tap, ci): coalesced reads.
+// one 64-element chunk of a weight gradient. idx enumerates the slab order (co, tap, ci): coalesced reads.
+// Vector form (channel counts that are multiples of 4, every layer but the stem): 16 element lanes x float4 by 16
+// slab lanes, each thread keeps up to 8 independent 16-byte loads in flight (the slabs are a pure HBM stream: 128
+// slabs of a fused 64-channel layer are 18.9 MB); scalar form: 64 element lanes x 4 slab lanes. LDS adds the slab
+// lanes in a fixed order (deterministic).
 __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* grad, int nsplit, int Cout, int Cin,
                                                    int ks, int Cout_real, int Cin_real, int kflat, int accumulate,
                                                    long long base, float (*red)[64]) {
   const int taps = ks * ks;
   const long long total = (long long)Cout_real * Cin_real * taps;
   const size_t slab_sz = (size_t)Cout * (kflat ? 1 : taps) * Cin;
+  const bool vec = ((Cin_real | Cin) & 3) == 0;
+  if (vec) {
+    const int el = (threadIdx.x & 15) * 4, sl = threadIdx.x >> 4;
+    const long long idx = base + el;
+    const bool ok = idx < total;          // total is a multiple of 4 here: a float4 is inside or outside as a whole
+    const int ci = (int)(idx % Cin_real);
+    const int t = (int)((idx / Cin_real) % taps);
+    const int co = (int)(idx / ((long long)Cin_real * taps));
+    const size_t soff = kflat ? ((size_t)co * Cin + (size_t)t * Cin_real + ci) : (((size_t)co * taps + t) * Cin + ci);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      const float* p = slabs + soff;
+      int k = sl;
+      for (; k + 112 < nsplit; k += 128) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(p + (size_t)(k + 16 * j) * slab_sz);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+      }
+      for (; k < nsplit; k += 16) {
+        const float4 v = *(const float4*)(p + (size_t)k * slab_sz);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    float (*red16)[64] = red;             // [16][64]
+    *(float4*)&red16[sl][el] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const long long id1 = base + threadIdx.x;
+      if (id1 < total) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sacc += red16[k][threadIdx.x];
+        const int ci1 = (int)(id1 % Cin_real);
+        const int t1 = (int)((id1 / Cin_real) % taps);
+        const int co1 = (int)(id1 / ((long long)Cin_real * taps));
+        float* g = grad + ((size_t)co1 * Cin_real + ci1) * taps + t1;
+        *g = accumulate ? *g + sacc : sacc;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long long idx = base + el;
   const bool ok = idx < total;
@@ -760,7 +838,7 @@ __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* gr
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
                                                            int Cout, int Cin, int ks, int Cout_real,
                                                            int Cin_real, int kflat, int accumulate) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   const long long total = (long long)Cout_real * Cin_real * ks * ks;
   for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64)
     wgrad_reduce_chunk(slabs, grad, nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, accumulate, base, red);
@@ -768,7 +846,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
 
 // every weight gradient of a backward segment in ONE launch: block b finds its layer by binary search
 __global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const HrWredEnt* tab, int n) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[16][64];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;

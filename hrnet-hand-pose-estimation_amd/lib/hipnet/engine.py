@@ -704,7 +704,9 @@ class Plan(object):
                     # y.g holds d(post-activation) summed over consumers -> d(raw), in place
                     self._bn_backward(y, C.ptr(y.g), None, 0, relu_of.get(id(y), False))
                 w = crec.mod.weight
-                if crec.mod.bias is not None:
+                # a bias in front of a batch-statistics BatchNorm has an exactly zero gradient (the BatchNorm-backward
+                # gradient sums to zero over every channel; autograd's value is rounding noise): no pass over dY
+                if crec.mod.bias is not None and not (bnrec is not None and self.training):
                     blocks = C.call('hrnet_reduce_blocks', 1, 1, y.pixels, y.C)
                     self.max_bwd_part = max(self.max_bwd_part, blocks * y.C)
                     i = self.bwd.add(C.OP_BIAS_GRAD, ints=(self.dtid, y.pixels, y.C, crec.Cout, 1),

@@ -115,8 +115,13 @@ def _grad_errors(model, ref64, other=None):
     return np.array(e_hip), np.array(e_oth), cos
 
 
-def test_train_forward_backward_matches_oracle_fp64():
+@pytest.mark.parametrize('stats', ['deterministic', 'atomic'])
+def test_train_forward_backward_matches_oracle_fp64(stats, monkeypatch):
     """fp32 device path, 128x128 crops, B=4: outputs, loss, running statistics, and EVERY gradient.
+    'deterministic' (HRNET_DETERMINISTIC=1: batch sums in a fixed order, bit-reproducible) is held to the tight
+    band; 'atomic' (the default: batch sums by float atomics) differs from run to run in the last bits of the
+    statistics, which this stack amplifies - measured over runs: cosine 0.99975..0.99995, worst tensor 0.07..0.27 -
+    and is held to a band that covers that spread.
 
     Gradients of this 60-layer ReLU/BatchNorm stack are chaotic at fp32: activations within ~1e-4 of
     zero flip their ReLU mask, so even the fp32 oracle differs from the fp64 oracle by 1e-3..1e-2 per
@@ -124,19 +129,22 @@ def test_train_forward_backward_matches_oracle_fp64():
     small multiple of the fp32 oracle's own error (median and 95th percentile), plus direction."""
     from hipnet import synth
     from oracle import hrnet_cpu as O
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1' if stats == 'deterministic' else '0')
     model, _, sd = make_model('fp32', 3)
     b = synth.rhd_batch(4, seed=99, img_h=128, img_w=128)
     r64 = _run_oracle(sd, O.W32_EXTRA, b, torch.float64)
     r32 = _run_oracle(sd, O.W32_EXTRA, b, torch.float32)
     hm, inter, loss = _run_hip(model, b)
+    assert model.hip().all_plans()[0].bn_sums == (stats == 'atomic')
     assert (hm.double() - r64['hm']).abs().max().item() <= 1e-3
     assert (inter.double() - r64['inter']).abs().max().item() <= 1e-3
     assert abs(loss - r64['loss']) <= 1e-5 * abs(r64['loss'])
     e_hip, e_o32, cos = _grad_errors(model, r64, r32)
-    assert cos >= 0.9999, cos
-    assert np.median(e_hip) <= 4 * np.median(e_o32) + 1e-4, (np.median(e_hip), np.median(e_o32))
-    assert np.percentile(e_hip, 95) <= 4 * np.percentile(e_o32, 95) + 1e-3
-    assert e_hip.max() <= 0.25
+    tight = stats == 'deterministic'
+    assert cos >= (0.9999 if tight else 0.9995), cos
+    assert np.median(e_hip) <= (4 if tight else 8) * np.median(e_o32) + 1e-4, (np.median(e_hip), np.median(e_o32))
+    assert np.percentile(e_hip, 95) <= (4 if tight else 6) * np.percentile(e_o32, 95) + 1e-3
+    assert e_hip.max() <= (0.25 if tight else 0.5)
     msd = model.state_dict()
     for k, v in r64['stats'].items():
         np.testing.assert_allclose(msd[k].cpu().numpy(), v.numpy(), rtol=1e-3, atol=1e-4, err_msg=k)
