@@ -23,6 +23,7 @@ class HrOp(ctypes.Structure):
 
 
 OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED, OP_BN_FINALIZE_TABLE = 17, 18, 19, 20, 21, 22
+OP_BWD_PW = 23
 LANE_SLOT = 18
 
 
@@ -74,6 +75,11 @@ _SIGS = {
     'hrnet_bwd_fused_supported': [_c_int] * 3,
     'hrnet_bwd_fused_splits': [_c_int] * 6,
     'hrnet_bwd_fused_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
+    'hrnet_conv1x1_bwd_fused': [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_i64, _c_int, _c_int] + [_c_vp],
+    'hrnet_bwd_pw_supported': [_c_int] * 3,
+    'hrnet_bwd_pw_rows_supported': [_c_int] * 3,
+    'hrnet_bwd_pw_splits': [_c_int, _c_i64, _c_int, _c_int],
+    'hrnet_bwd_pw_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_splits': [_c_int] * 8,
     'hrnet_wgrad_tiles': [_c_int] * 8,
     'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],
@@ -113,6 +119,7 @@ _SIGS = {
 }
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
+          'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 

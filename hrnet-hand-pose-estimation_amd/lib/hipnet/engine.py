@@ -628,8 +628,12 @@ class Plan(object):
             if ti in fused_at:
                 if e[4] is self.inter_act and self.inter_gop is None:
                     self.inter_gop = len(self.bwd)
-                self._fused_block_backward(ti, lane, in_region)
-                fused_skip.update((ti - 1, ti - 2))
+                if fused_at[ti] == 'bottleneck':
+                    self._fused_bottleneck_backward(ti, lane, in_region)
+                    fused_skip.update((ti - 1, ti - 2, ti - 3))
+                else:
+                    self._fused_block_backward(ti, lane, in_region)
+                    fused_skip.update((ti - 1, ti - 2))
                 continue
             if e[0] in ('fork', 'join'):
                 # a forward join is the backward fork of the same lanes, and vice versa
@@ -790,8 +794,9 @@ class Plan(object):
 
     # ---- fused backward of a BasicBlock (conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU: pose_hrnet.py:41-57) ----
     def _find_fused_blocks(self):
-        """tape indices of the 'sum' entries that close a BasicBlock both of whose convs the fused kernel serves"""
-        out = set()
+        """tape indices of the 'sum' entries that close a BasicBlock (or an identity Bottleneck) all of whose convs
+        the fused kernels serve -> 'basic' / 'bottleneck'"""
+        out = {}
         if not self.training or os.environ.get('HRNET_FUSED_BWD', '1') == '0':
             return out
         T, L = self.tape, self.tape_lanes
@@ -820,7 +825,38 @@ class Plan(object):
             ps = self._producer_sum.get(id(x))
             ok = ok and (xin1.relu or (xin1.bn is None and ps is not None and ps[3]))
             if ok:
-                out.add(ti)
+                out[ti] = 'basic'
+        # Bottleneck with an identity residual (pose_hrnet.py:60-105; layer1 blocks 1..3): conv1 1x1, conv2 3x3,
+        # conv3 1x1, + x, ReLU - the pointwise convs through hrnet_conv1x1_bwd_fused
+        if os.environ.get('HRNET_FUSED_PW', '1') != '0':
+            for ti in range(3, len(T)):
+                e = T[ti]
+                if e[0] != 'sum' or any(T[ti - k][0] != 'conv' for k in (1, 2, 3)):
+                    continue
+                _, terms, shifts, relu_out, res = e
+                _, xin3, crec3, st3, y3, bn3 = T[ti - 1]
+                _, xin2, crec2, st2, y2, bn2 = T[ti - 2]
+                _, xin1, crec1, st1, y1, bn1 = T[ti - 3]
+                if not (len(terms) == 2 and list(shifts) == [0, 0] and relu_out
+                        and L[ti] == L[ti - 1] == L[ti - 2] == L[ti - 3]):
+                    continue
+                c, idt = terms
+                x = xin1.act
+                ps = self._producer_sum.get(id(x))
+                ok = (c.act is y3 and c.bn is bn3 and bn3 is not None and not c.relu and y3.nuse == 1
+                      and xin3.act is y2 and xin3.bn is bn2 and bn2 is not None and xin3.relu and y2.nuse == 1
+                      and xin2.act is y1 and xin2.bn is bn1 and bn1 is not None and xin2.relu and y1.nuse == 1
+                      and idt.act is x and idt.bn is None and not idt.relu and xin1.bn is None and x.nuse == 2
+                      and ps is not None and ps[3]
+                      and st1 == st2 == st3 == 1 and (crec1.ks, crec2.ks, crec3.ks) == (1, 3, 1)
+                      and not (crec1.stem or crec2.stem or crec3.stem)
+                      and crec1.mod.bias is None and crec2.mod.bias is None and crec3.mod.bias is None
+                      and x.g is not None and x is not self.inter_act
+                      and C.call('hrnet_bwd_pw_supported', self.dtid, y2.C, y3.C)
+                      and C.call('hrnet_bwd_fused_supported', self.dtid, y1.C, y2.C)
+                      and C.call('hrnet_bwd_pw_supported', self.dtid, x.C, y1.C))
+                if ok:
+                    out[ti] = 'bottleneck'
         return out
 
     def _bn_bwd_finalize(self, y, reduce_from=None):
@@ -843,33 +879,86 @@ class Plan(object):
         y.bn_done = True
 
     def _fused_conv_bwd(self, dz, y, xin, crec, dx, addend, mask_out, rows_for, lane):
-        """one hrnet_conv3x3_bwd_fused launch: backward of `y = conv(xin)` given the masked gradient `dz` of y's
-        BatchNorm output; writes the gradient of xin's activation into `dx` and y's weight-gradient slabs"""
+        """one hrnet_conv3x3_bwd_fused / hrnet_conv1x1_bwd_fused launch: backward of `y = conv(xin)` given the masked
+        gradient `dz` of y's BatchNorm output; writes the gradient of xin's activation into `dx` and y's
+        weight-gradient slabs. rows_for: the raw activation whose BatchNorm-backward sums the launch gathers."""
         net, x = self.net, xin.act
-        ns = C.call('hrnet_bwd_fused_splits', self.dtid, x.N, x.H, x.W, x.C, y.C)
-        slabs = self._f32(ns * y.C * 9 * x.C)
+        ks = crec.ks
+        if ks == 3:
+            ns = C.call('hrnet_bwd_fused_splits', self.dtid, x.N, x.H, x.W, x.C, y.C)
+            kind = C.OP_BWD_FUSED
+        else:
+            ns = C.call('hrnet_bwd_pw_splits', self.dtid, x.pixels, x.C, y.C)
+            kind = C.OP_BWD_PW
+            if rows_for is not None and not C.call('hrnet_bwd_pw_rows_supported', self.dtid, x.C, y.C):
+                rows_for = None               # (the BatchNorm backward behind it runs its own reduction pass)
+        slabs = self._f32(ns * y.C * ks * ks * x.C)
         self.slab_bytes += slabs.numel() * 4
         rows = None
         if rows_for is not None:
             rows = self._f32(ns * 2 * x.C)
             rows_for.bwd_rows = (rows, ns)
             self.n_fused_bwdstats += 1
-        self.bwd.add(C.OP_BWD_FUSED,
+        self.bwd.add(kind,
                      ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0),
                      ptrs=(dz, C.ptr(y.t), C.ptr(y.bn.coef), C.ptr(x.t),
                            C.ptr(xin.bn.scale) if xin.bn else None, C.ptr(xin.bn.shift) if xin.bn else None,
                            C.ptr(crec.wd), dx, addend, C.ptr(rows),
                            C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs)))
         w = crec.mod.weight
-        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=3,
+        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
                    Cout=crec.Cout, Cin=crec.Cin, kflat=0, accumulate=1)
         if self.batch_wred:
             self._wred.setdefault(lane, []).append(ent)
             if lane == 0:
-                self._wred_bytes += crec.Cout * crec.Cin * 9 * 4
+                self._wred_bytes += crec.Cout * crec.Cin * ks * ks * 4
         else:
-            self.bwd.add(C.OP_WGRAD_REDUCE, ints=(ns, y.C, x.C, 3, crec.Cout, crec.Cin, 0, 1),
+            self.bwd.add(C.OP_WGRAD_REDUCE, ints=(ns, y.C, x.C, ks, crec.Cout, crec.Cin, 0, 1),
                          ptrs=(C.ptr(slabs), C.ptr(net.grad_of(w))))
+
+    def _rows_target(self, x, xin):
+        """the raw activation behind x whose BatchNorm backward needs (sum dz, sum dz*y) of x's gradient"""
+        if x is self.inter_act:
+            return None
+        if xin.bn is not None:
+            return x                             # x is a raw conv output read through its BatchNorm + ReLU
+        ps = self._producer_sum.get(id(x))
+        cand = [t for t, sh in zip(ps[1], ps[2])
+                if t.act.bn is not None and t.act.nuse == 1 and sh == 0 and not t.relu] if ps else []
+        return cand[0].act if cand else None
+
+    def _fused_bottleneck_backward(self, ti, lane, in_region):
+        """identity Bottleneck: three fused launches (conv3 1x1, conv2 3x3, conv1 1x1 + residual stream)"""
+        _, terms, shifts, relu_out, out = self.tape[ti]
+        _, xin3, crec3, _, y3, bn3 = self.tape[ti - 1]
+        _, xin2, crec2, _, y2, bn2 = self.tape[ti - 2]
+        _, xin1, crec1, _, y1, bn1 = self.tape[ti - 3]
+        x = xin1.act
+        self.bwd.tags[len(self.bwd)] = crec3.prefix
+        if not out.ginit:
+            raise RuntimeError('no gradient reaches ' + out.name)
+        assert not x.ginit and not y1.ginit and not y2.ginit and not y3.ginit
+        if not out.gmasked:
+            self.bwd.add(C.OP_GRAD_TERM, ints=(self.dtid, out.N, out.H, out.W, out.C, 0, 0, 0, 0),
+                         ptrs=(C.ptr(out.g), C.ptr(out.g), C.ptr(out.t), None, None, None, None, None))
+            out.gmasked = True
+        # conv3: dz = d(out) masked (also the identity branch's gradient); its input is relu(bn2(y2))
+        self._bn_bwd_finalize(y3, reduce_from=C.ptr(out.g))
+        self._fused_conv_bwd(C.ptr(out.g), y3, xin3, crec3, C.ptr(y2.g), None, True, y2, lane)
+        y2.ginit = y2.gmasked = True
+        y3.ginit = True
+        self.bwd.tags[len(self.bwd)] = crec2.prefix
+        self._bn_bwd_finalize(y2, reduce_from=C.ptr(y2.g))
+        self._fused_conv_bwd(C.ptr(y2.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane)
+        y1.ginit = y1.gmasked = True
+        # conv1: its input is the block input x; the residual stream (the masked d(out)) joins before the mask
+        self.bwd.tags[len(self.bwd)] = crec1.prefix
+        self._bn_bwd_finalize(y1, reduce_from=C.ptr(y1.g))
+        self._fused_conv_bwd(C.ptr(y1.g), y1, xin1, crec1, C.ptr(x.g), C.ptr(out.g), True,
+                             self._rows_target(x, xin1), lane)
+        x.ginit = x.gmasked = True
+        if lane == 0 and not in_region:
+            self._bucket_mark_after_conv(crec1)
 
     def _fused_block_backward(self, ti, lane, in_region):
         _, terms, shifts, relu_out, out = self.tape[ti]

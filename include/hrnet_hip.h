@@ -62,7 +62,8 @@ enum {
   HR_OP_STREAM_WAIT = 19,  /* p[0] = event, the op's lane waits for it */
   HR_OP_WGRAD_REDUCE_TABLE = 20, /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
   HR_OP_BWD_FUSED = 21,    /* hrnet_conv3x3_bwd_fused */
-  HR_OP_BN_FINALIZE_TABLE = 22 /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
+  HR_OP_BN_FINALIZE_TABLE = 22, /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
+  HR_OP_BWD_PW = 23        /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -180,6 +181,24 @@ int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y, const floa
 int hrnet_bwd_fused_supported(int dtype, int Cin, int Cout);
 int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, int Cout);
 int hrnet_bwd_fused_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen);
+
+/*
+ * The same fused backward for a 1x1 (pointwise) convolution: the conv1 / conv3 / downsample layers of a
+ * Bottleneck (autograd of pose_hrnet.py:60-105). Pixels are a flat index: dz, y [pixels,Cout]; x, dx, addend,
+ * bs_y [pixels,Cin]; wT = hrnet_pack_weights(mode 1) of the 1x1 kernel ([Cin][Cout]); slabs
+ * [hrnet_bwd_pw_splits()][Cout][Cin] f32 (sum with hrnet_wgrad_reduce, ks = 1). bf16 only; served shapes
+ * (Cin,Cout) = (64,256), (256,64), (64,64): hrnet_bwd_pw_supported(). `rows` (the next BatchNorm's backward sums,
+ * [splits][2][Cin]) only where hrnet_bwd_pw_rows_supported() (Cin <= 64); otherwise pass NULL and run
+ * hrnet_bn_bwd_reduce on dx.
+ */
+int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x,
+                            const float* in_scale, const float* in_shift, int in_relu, const void* wT, void* dx,
+                            const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
+                            long long pixels, int Cin, int Cout, hr_stream_t stream);
+int hrnet_bwd_pw_supported(int dtype, int Cin, int Cout);
+int hrnet_bwd_pw_rows_supported(int dtype, int Cin, int Cout);
+int hrnet_bwd_pw_splits(int dtype, long long pixels, int Cin, int Cout);
+int hrnet_bwd_pw_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen);
 
 /*
  * Pack f32 OIHW master weights into the kernels' layout.
