@@ -594,7 +594,11 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   // beat 256 by 0.6 ms/step (20.6 vs 21.3 ms; 64: 22.0, 96: 22.0, 160: 20.7) - a grid that takes every CU with a
   // 100 KB / 256-VGPR workgroup locks the other lanes' kernels out - and it halves the slab traffic
   static const int cus = getenv("HRNET_FUSED_CUS") ? atoi(getenv("HRNET_FUSED_CUS")) : 128;
-  int ns = cus * c.per_cu / ncb;
+  // ... except where the launch is the whole step for a while: the 64-channel 3x3 conv of a layer1 Bottleneck
+  // (64x64 maps: 2048 workgroup-tiles at batch 64) sits in the single-lane tail of the backward pass and takes
+  // every CU (165 us on 128 CUs)
+  static const int big = getenv("HRNET_FUSED_CUS_BIG") ? atoi(getenv("HRNET_FUSED_CUS_BIG")) : 256;
+  int ns = ((long long)tiles * ncb >= 2048 ? big : cus) * c.per_cu / ncb;
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   // even walks: every split takes the same number of tiles when possible

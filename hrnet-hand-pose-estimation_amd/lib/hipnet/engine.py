@@ -732,7 +732,17 @@ class Plan(object):
                                ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
                                accumulate=1)
                     if self.defer_wgrad and in_region and first_fork is not None and ti > first_fork:
-                        # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends
+                        # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends.
+                        # A deferred launch runs in the background of the single-lane tail: it does not need the
+                        # parallelism of many splits, and every split is a slab written and read back
+                        div = int(os.environ.get('HRNET_DEFER_SPLIT_DIV', '4'))   # measured: 1: 19.97 ms/step, 2: 19.56, 4: 19.49, 8: 19.97
+                        if div > 1 and nsplit > 1:
+                            tiles = C.call('hrnet_wgrad_tiles', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
+                            ns2 = max(1, nsplit // div)
+                            while ns2 > 1 and tiles % ns2 != 0:
+                                ns2 -= 1
+                            wints = wints[:11] + (ns2,)
+                            ent['nsplit'] = ns2
                         self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
                     else:
                         self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
