@@ -81,6 +81,9 @@ def conv_flops_table(plan):
                 # weight gradient + input gradient of one 3x3 conv in one launch: 2 x the forward conv's FLOPs
                 C.call('hrnet_bwd_fused_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5] * 9)
+            elif op.kind == C.OP_BWD_PW:
+                C.call('hrnet_bwd_pw_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
+                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5])
             elif op.kind == C.OP_WGRAD:
                 C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[4], op.i[8], op.i[9], buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, True))
@@ -99,8 +102,12 @@ def traffic_of(kernel_name):
     table = json.load(open(files[-1]))
     m = re.match(r'(conv_bs|conv_fwdb|conv_fwd|conv_dg|conv|wgrad|bwd_fused)_kernel<[^,]+, (.*)>', kernel_name)
     if not m:
-        return None
-    key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])
+        m = re.match(r'(bwd_pw)_kernel<()(.*)>', kernel_name)
+        if not m:
+            return None
+        key = '|'.join(['bwd_pw'] + [p.strip() for p in m.group(3).split(',')])
+    else:
+        key = '|'.join([m.group(1)] + [p.strip() for p in m.group(2).split(',')])
     row = table.get(key)
     return row['hbm_bytes_per_launch'] if row else None
 
@@ -434,6 +441,10 @@ def main():
             'algorithmic_gflop_per_img': round(mfma_fl / args.batch / 1e9, 2)}
         extra_out['kernel_ms'] = {k: [v[0], round(v[1], 3)] for k, v in
                                   sorted(stats.items(), key=lambda kv: -kv[1][1])}
+        plan_ = model.hip().plan(x.shape[0], x.shape[2], x.shape[3], True, True)
+        extra_out['launches_per_step'] = {'fwd': len(plan_.fwd), 'bwd': len(plan_.bwd),
+                                          'fused_blocks': plan_.n_fused_blocks, 'deferred_wgrads': plan_.n_deferred_wgrads}
+        extra_out['wgrad_slab_mb_per_step'] = round(plan_.slab_bytes / 1e6, 1)
         extra_out['critical_path_ms'] = kinds.pop('critical_path_ms')
         extra_out['op_kind_ms'] = {str(k): [v[0], round(v[1], 3)] for k, v in sorted(kinds.items())}
 

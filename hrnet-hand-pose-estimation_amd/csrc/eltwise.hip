@@ -662,9 +662,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, T* ou
   }
 }
 
-// all convolutions of the network packed by ONE launch: block b finds its entry by binary search
+// all convolutions of the network packed by ONE launch: block b finds its entry by binary search.
+// The master weights are OIHW f32; both packed layouts permute (ci, tap) or transpose (co <-> ci), so a direct
+// gather reads 4 bytes per 36-byte (or row-sized) stride - 5.7x read amplification measured (653 MB fetched for
+// 114 MB of weights, 130 us per launch, twice per step). Here a block stages a contiguous piece of the master
+// through LDS: mode 0 one output-channel row (Cin*taps floats, contiguous), mode 1 four input channels of every
+// output channel (4*taps contiguous floats per row), and writes its packed rows with unit stride.
+constexpr int PACK_LDS_FLOATS = 19456;      // 76 KB: mode 1 needs Cout * (4*taps + 1) floats (Cout <= 512 at 3x3)
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, int n) {
+  __shared__ float buf[PACK_LDS_FLOATS];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -672,31 +680,51 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, i
   }
   const HrPackEnt e = tab[lo];
   const int taps = e.ks * e.ks;
-  const long long total = e.mode == 2 ? (long long)e.Cout_pad * e.Cin_pad : (long long)e.Cout_pad * taps * e.Cin_pad;
   const float* w = (const float*)e.w;
   T* out = (T*)e.out;
-  const long long base = (long long)((int)blockIdx.x - e.block0) * 1024;
+  const int u = (int)blockIdx.x - e.block0;
+  if (e.mode == 0) {
+    // out[co][t][ci_pad] <- w[co][ci][t]
+    const int co = u, rowlen = e.Cin * taps;
+    if (co < e.Cout)
+      for (int i = threadIdx.x; i < rowlen; i += 256) buf[i] = w[(size_t)co * rowlen + i];
+    __syncthreads();
+    T* o = out + (size_t)co * taps * e.Cin_pad;
+    for (int idx = threadIdx.x; idx < taps * e.Cin_pad; idx += 256) {
+      const int t = idx / e.Cin_pad, ci = idx - t * e.Cin_pad;
+      o[idx] = (T)((co < e.Cout && ci < e.Cin) ? buf[ci * taps + t] : 0.f);
+    }
+  } else if (e.mode == 1) {
+    // out[ci][taps flipped][co_pad] <- w[co][ci][t]
+    const int ci0 = u * 4, span = 4 * taps, pitch = span + 1;
+    const int nci = e.Cin_pad - ci0 < 4 ? e.Cin_pad - ci0 : 4;
+    for (int i = threadIdx.x; i < e.Cout * span; i += 256) {
+      const int co = i / span, r = i - co * span;
+      const int ci = ci0 + r / taps;
+      buf[co * pitch + r] = ci < e.Cin ? w[((size_t)co * e.Cin + ci0) * taps + r] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nci * taps * e.Cout_pad; idx += 256) {
+      const int co = idx % e.Cout_pad;
+      const int tf = (idx / e.Cout_pad) % taps;
+      const int cl = idx / (e.Cout_pad * taps);
+      out[((size_t)(ci0 + cl) * taps + tf) * e.Cout_pad + co] =
+          (T)(co < e.Cout ? buf[co * pitch + cl * taps + (taps - 1 - tf)] : 0.f);
+    }
+  } else {
+    // stem: out[co][k_pad], k = tap * Cin + ci (a few KB)
+    const long long total = (long long)e.Cout_pad * e.Cin_pad;
+    const long long base = (long long)u * 1024;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long idx = base + r * 256 + threadIdx.x;
-    if (idx >= total) break;
-    float val = 0.f;
-    if (e.mode == 0) {
-      const int ci = (int)(idx % e.Cin_pad);
-      const int t = (int)((idx / e.Cin_pad) % taps);
-      const int co = (int)(idx / ((long long)e.Cin_pad * taps));
-      if (co < e.Cout && ci < e.Cin) val = w[((size_t)co * e.Cin + ci) * taps + t];
-    } else if (e.mode == 1) {
-      const int co = (int)(idx % e.Cout_pad);
-      const int tf = (int)((idx / e.Cout_pad) % taps);
-      const int ci = (int)(idx / ((long long)e.Cout_pad * taps));
-      if (co < e.Cout && ci < e.Cin) val = w[((size_t)co * e.Cin + ci) * taps + (taps - 1 - tf)];
-    } else {
+    for (int r = 0; r < 4; ++r) {
+      const long long idx = base + r * 256 + threadIdx.x;
+      if (idx >= total) break;
       const int k = (int)(idx % e.Cin_pad);
       const int co = (int)(idx / e.Cin_pad);
+      float val = 0.f;
       if (co < e.Cout && k < taps * e.Cin) val = w[((size_t)co * e.Cin + (k % e.Cin)) * taps + k / e.Cin];
+      out[idx] = (T)val;
     }
-    out[idx] = (T)val;
   }
 }
 
@@ -981,6 +1009,13 @@ int hr_launch_grad_term(const HrOp& op, hipStream_t s) {
   else
     hipLaunchKernelGGL(grad_term_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a);
   return hr_check_launch("grad_term");
+}
+
+extern "C" int hrnet_pack_blocks(int Cout_pad, int Cin_pad, int ks, int mode) {
+  if (mode == 0) return Cout_pad;
+  if (mode == 1) return (Cin_pad + 3) / 4;
+  (void)ks;
+  return (int)(((long long)Cout_pad * Cin_pad + 1023) / 1024);
 }
 
 extern "C" int hrnet_reduce_blocks(int N, int H, int W, int C) {

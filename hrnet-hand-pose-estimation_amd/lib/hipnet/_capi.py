@@ -77,6 +77,7 @@ _SIGS = {
     'hrnet_bwd_fused_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
     'hrnet_conv1x1_bwd_fused': [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_i64, _c_int, _c_int] + [_c_vp],
     'hrnet_bwd_pw_supported': [_c_int] * 3,
+    'hrnet_pack_blocks': [_c_int] * 4,
     'hrnet_bwd_pw_rows_supported': [_c_int] * 3,
     'hrnet_bwd_pw_splits': [_c_int, _c_i64, _c_int, _c_int],
     'hrnet_bwd_pw_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
@@ -119,7 +120,7 @@ _SIGS = {
 }
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
-          'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
+          'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 

@@ -721,6 +721,17 @@ class Plan(object):
                     self.bwd.sync(lane, self.wlane)
                     self.bwd.lane = self.wlane
                 nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
+                deferred = (self.batch_wred and self.defer_wgrad and in_region and first_fork is not None
+                            and ti > first_fork)
+                if deferred and nsplit > 1:
+                    # A deferred launch runs in the background of the single-lane tail: it does not need the
+                    # parallelism of many splits, and every split is a slab written and read back.
+                    # measured (ms/step): divisor 1: 19.97, 2: 19.56, 4: 19.49, 8: 19.97
+                    div = int(os.environ.get('HRNET_DEFER_SPLIT_DIV', '4'))
+                    tiles = C.call('hrnet_wgrad_tiles', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
+                    nsplit = max(1, nsplit // max(div, 1))
+                    while nsplit > 1 and tiles % nsplit != 0:
+                        nsplit -= 1
                 wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit)
                 wptrs = [C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
                          C.ptr(xin.bn.shift) if xin.bn else None, None]
@@ -731,18 +742,8 @@ class Plan(object):
                     ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
                                ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
                                accumulate=1)
-                    if self.defer_wgrad and in_region and first_fork is not None and ti > first_fork:
-                        # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends.
-                        # A deferred launch runs in the background of the single-lane tail: it does not need the
-                        # parallelism of many splits, and every split is a slab written and read back
-                        div = int(os.environ.get('HRNET_DEFER_SPLIT_DIV', '4'))   # measured: 1: 19.97 ms/step, 2: 19.56, 4: 19.49, 8: 19.97
-                        if div > 1 and nsplit > 1:
-                            tiles = C.call('hrnet_wgrad_tiles', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
-                            ns2 = max(1, nsplit // div)
-                            while ns2 > 1 and tiles % ns2 != 0:
-                                ns2 -= 1
-                            wints = wints[:11] + (ns2,)
-                            ent['nsplit'] = ns2
+                    if deferred:
+                        # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends
                         self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
                     else:
                         self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)

@@ -82,11 +82,13 @@ class HipNet(object):
         block = 0
         for e, (r, mode, out) in zip(ents, items):
             taps = r.ks * r.ks
-            total = r.Cout_pad * r.Cin_pad if mode == 2 else r.Cout_pad * taps * r.Cin_pad
+            if mode == 1 and r.Cout * (4 * taps + 1) > 19456:
+                raise ValueError('{}: {} output channels at {}x{} exceed the LDS staging of the weight packer'.format(
+                    r.prefix, r.Cout, r.ks, r.ks))
             e.w, e.out = C.ptr(r.mod.weight), C.ptr(out)
             e.Cout, e.Cin, e.ks, e.Cout_pad, e.Cin_pad, e.mode = r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, mode
             e.block0 = block
-            block += (total + 1023) // 1024
+            block += C.call('hrnet_pack_blocks', r.Cout_pad, r.Cin_pad, r.ks, mode)
         raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._tables = getattr(self, '_tables', []) + [table]

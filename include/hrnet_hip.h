@@ -209,7 +209,8 @@ int hrnet_bwd_pw_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen
 int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, int Cout, int Cin, int ks,
                        int Cout_pad, int Cin_pad, int mode, hr_stream_t stream);
 /* The same for every convolution of a network in ONE launch: `table` is a DEVICE array of n
- * entries; entry e covers blocks [block0, block0 + ceil(elements/1024)); total_blocks = their sum. */
+ * entries; entry e covers blocks [block0, block0 + hrnet_pack_blocks(Cout_pad, Cin_pad, ks, mode));
+ * total_blocks = their sum. Mode 1 stages Cout * (4*ks*ks + 1) floats per block in LDS: at most 19456. */
 typedef struct HrPackEnt {
   const void* w;   /* f32 OIHW master weights */
   void* out;       /* packed weights */
@@ -217,6 +218,7 @@ typedef struct HrPackEnt {
 } HrPackEnt;
 int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n, int total_blocks,
                              hr_stream_t stream);
+int hrnet_pack_blocks(int Cout_pad, int Cin_pad, int ks, int mode);
 
 /* hrnet_wgrad_reduce for many convolutions in ONE launch (each layer keeps its own slab region):
  * `table` is a DEVICE array of n entries; entry e covers blocks [block0, block0 +

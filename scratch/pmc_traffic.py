@@ -5,6 +5,16 @@ import csv, glob, collections, json, re, sys
 
 def canon(name):
     """canonical key 'conv|3|1|8|8|32|2|2|2' from rocprofv3's (sometimes mis-demangled) kernel names"""
+    if 'bwd_fused_kernel' in name and 'dcn' not in name:
+        if name.startswith('_ZN'):
+            ints = re.findall(r'Li(\d+)E', name) + ['true' if 'Lb1E' in name else 'false']
+        else:
+            body = name[name.index('<') + 1:name.rindex('>')]
+            ints = [q.strip() for q in body.split(',')][1:]
+        return '|'.join(['bwd_fused'] + ints)
+    if 'bwd_pw_kernel' in name:
+        ints = re.findall(r'Li(\d+)E', name) if name.startswith('_ZN') else [q.strip() for q in name[name.index('<') + 1:name.rindex('>')].split(',')]
+        return '|'.join(['bwd_pw'] + ints)
     kind = ('conv' if 'conv_kernel' in name else 'conv_bs' if 'conv_bs_kernel' in name else
             'conv_fwd' if 'conv_fwd_kernel' in name else 'conv_fwdb' if 'conv_fwdb_kernel' in name else 'conv_dg' if 'conv_dg_kernel' in name else
             'wgrad' if 'wgrad_kernel' in name else None)

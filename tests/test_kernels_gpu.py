@@ -240,6 +240,37 @@ def test_bn_finalize_train_and_eval(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_pack_table_matches_the_per_layer_pack(dtype):
+    """hrnet_pack_weights_table (every conv of the network in one launch, rows staged through LDS) against
+    hrnet_pack_weights layer by layer, bit for bit: forward layout, transposed/flipped input-gradient layout and
+    the flattened stem, with padded and unpadded channel counts (17 joints -> 32, 3 -> 8, 480, 48-wide branches)."""
+    import ctypes
+    hh = _h()
+    from hipnet import _capi as C
+    g = torch.Generator().manual_seed(77)
+    shapes = [(64, 3, 3, 2), (32, 32, 3, 0), (32, 32, 3, 1), (64, 256, 1, 0), (64, 256, 1, 1), (17, 480, 1, 0),
+              (17, 480, 1, 1), (480, 480, 1, 1), (384, 384, 3, 1), (384, 192, 3, 0), (48, 96, 3, 1), (21, 20, 3, 0),
+              (21, 20, 3, 1)]
+    ws, outs, wants = [], [], []
+    ents = (C.HrPackEnt * len(shapes))()
+    block = 0
+    for e, (co, ci, ks, mode) in zip(ents, shapes):
+        w = torch.randn(co, ci, ks, ks, generator=g)
+        want, cop, cip = hh.pack_weights(w, dtype, mode=mode)
+        wd = w.to(hh.DEV).contiguous()
+        out = torch.full_like(want, float('nan'))
+        ws.append(wd); outs.append(out); wants.append(want)
+        e.w, e.out = wd.data_ptr(), out.data_ptr()
+        e.Cout, e.Cin, e.ks, e.Cout_pad, e.Cin_pad, e.mode, e.block0 = co, ci, ks, cop, cip, mode, block
+        block += C.call('hrnet_pack_blocks', cop, cip, ks, mode)
+    raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(hh.DEV)
+    C.call('hrnet_pack_weights_table', hh.dt_id(dtype), table.data_ptr(), len(shapes), block, C.stream_ptr())
+    for shp, out, want in zip(shapes, outs, wants):
+        assert torch.equal(out.float().cpu(), want.float().cpu()), shp
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_consumer_side_batchnorm_conv_sum_and_table_finalize(dtype):
     """hrnet_conv2d_bnref / hrnet_sum_terms_bnref / hrnet_bn_finalize_table: a conv accumulates its batch sums with
     float atomics; the next conv and a residual sum read that output through BatchNorm(+ReLU) built on the fly from
