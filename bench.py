@@ -473,6 +473,8 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         out.update(extra_out)
+        if sync is not None:
+            out['dp_exchange'] = sync.describe()     # RCCL all-reduce buckets: where the backward program is cut
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

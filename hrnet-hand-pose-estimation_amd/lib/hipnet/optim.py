@@ -127,6 +127,18 @@ class GradSync(object):
         self._end = len(plan.bwd)
         self._plan = plan
 
+    def describe(self):
+        """the exchange plan of the last backward program: op index of every cut and the f32 range it sends"""
+        if self._plan is None:
+            return None
+        rows = [{'after_op': int(i), 'offset': int(lo), 'floats': int(hi - lo), 'mb': round((hi - lo) * 4 / 1e6, 2)}
+                for i, (lo, hi) in sorted(self._ranges.items())]
+        rows.append({'after_op': int(self._end), 'offset': int(self._tail[0]),
+                     'floats': int(self._tail[1] - self._tail[0]),
+                     'mb': round((self._tail[1] - self._tail[0]) * 4 / 1e6, 2)})
+        return {'payload': 'f32', 'bucket_bytes_min': int(self.bucket_bytes), 'backward_ops': int(self._end),
+                'buckets': rows}
+
     def begin(self, plan):
         if self._plan is not plan:
             self._prepare(plan)

@@ -167,6 +167,11 @@ def _gradsync_worker(rank, world, port, q):
         sync.after(c)
     sync.finish()
     ok = bool(torch.all(net.flat_g == total)) and opt.grad_scale == 1.0 / world
+    # the plan bench.py prints at N>1: every float of the flat gradient in exactly one bucket, >= 8000 bytes each
+    d = sync.describe()
+    spans = sorted((b['offset'], b['offset'] + b['floats']) for b in d['buckets'])
+    ok = ok and d['payload'] == 'f32' and spans[0][0] == 0 and spans[-1][1] == 6000
+    ok = ok and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     # (2) any other optimizer (torch.optim.SGD ...): finish() leaves the MEAN, as DDP does
     net.flat_g.fill_(float(rank + 1))
     sync = GradSync(FakeModel(), optimizer=object(), bucket_bytes=8000, broadcast=False)
