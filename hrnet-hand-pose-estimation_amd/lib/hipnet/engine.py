@@ -631,6 +631,9 @@ class Plan(object):
                 if fused_at[ti] == 'bottleneck':
                     self._fused_bottleneck_backward(ti, lane, in_region)
                     fused_skip.update((ti - 1, ti - 2, ti - 3))
+                elif fused_at[ti] == 'bottleneck_ds':
+                    self._fused_bottleneck_backward(ti, lane, in_region, downsample=True)
+                    fused_skip.update((ti - 1, ti - 2, ti - 3, ti - 4))
                 else:
                     self._fused_block_backward(ti, lane, in_region)
                     fused_skip.update((ti - 1, ti - 2))
@@ -868,6 +871,38 @@ class Plan(object):
                       and C.call('hrnet_bwd_pw_supported', self.dtid, x.C, y1.C))
                 if ok:
                     out[ti] = 'bottleneck'
+            # ... and the first Bottleneck of layer1, whose residual is a 1x1 conv + BatchNorm of the same input
+            # (pose_hrnet.py:98-99: downsample): conv1, conv2, conv3, downsample, sum
+            for ti in range(4, len(T)):
+                e = T[ti]
+                if e[0] != 'sum' or any(T[ti - k][0] != 'conv' for k in (1, 2, 3, 4)):
+                    continue
+                _, terms, shifts, relu_out, res = e
+                _, xind, crecd, std, yd, bnd = T[ti - 1]
+                _, xin3, crec3, st3, y3, bn3 = T[ti - 2]
+                _, xin2, crec2, st2, y2, bn2 = T[ti - 3]
+                _, xin1, crec1, st1, y1, bn1 = T[ti - 4]
+                if not (len(terms) == 2 and list(shifts) == [0, 0] and relu_out
+                        and len({L[ti - k] for k in range(5)}) == 1):
+                    continue
+                c, d = terms
+                x = xin1.act
+                ok = (c.act is y3 and c.bn is bn3 and bn3 is not None and not c.relu and y3.nuse == 1
+                      and d.act is yd and d.bn is bnd and bnd is not None and not d.relu and yd.nuse == 1
+                      and xin3.act is y2 and xin3.bn is bn2 and bn2 is not None and xin3.relu and y2.nuse == 1
+                      and xin2.act is y1 and xin2.bn is bn1 and bn1 is not None and xin2.relu and y1.nuse == 1
+                      and xind.act is x and xind.bn is xin1.bn and xind.relu == xin1.relu and xin1.relu
+                      and xin1.bn is not None and x.nuse == 2
+                      and st1 == st2 == st3 == std == 1 and (crec1.ks, crec2.ks, crec3.ks, crecd.ks) == (1, 3, 1, 1)
+                      and not (crec1.stem or crec2.stem or crec3.stem or crecd.stem)
+                      and all(cr.mod.bias is None for cr in (crec1, crec2, crec3, crecd))
+                      and x.g is not None and x is not self.inter_act
+                      and C.call('hrnet_bwd_pw_supported', self.dtid, y2.C, y3.C)
+                      and C.call('hrnet_bwd_pw_supported', self.dtid, x.C, yd.C)
+                      and C.call('hrnet_bwd_fused_supported', self.dtid, y1.C, y2.C)
+                      and C.call('hrnet_bwd_pw_supported', self.dtid, x.C, y1.C))
+                if ok:
+                    out[ti] = 'bottleneck_ds'
         return out
 
     def _bn_bwd_finalize(self, y, reduce_from=None):
@@ -938,12 +973,14 @@ class Plan(object):
                 if t.act.bn is not None and t.act.nuse == 1 and sh == 0 and not t.relu] if ps else []
         return cand[0].act if cand else None
 
-    def _fused_bottleneck_backward(self, ti, lane, in_region):
-        """identity Bottleneck: three fused launches (conv3 1x1, conv2 3x3, conv1 1x1 + residual stream)"""
+    def _fused_bottleneck_backward(self, ti, lane, in_region, downsample=False):
+        """Bottleneck: fused launches for conv3 1x1, conv2 3x3, conv1 1x1 (+ the residual stream: the identity's
+        masked gradient, or the input gradient of the downsample conv written first)"""
         _, terms, shifts, relu_out, out = self.tape[ti]
-        _, xin3, crec3, _, y3, bn3 = self.tape[ti - 1]
-        _, xin2, crec2, _, y2, bn2 = self.tape[ti - 2]
-        _, xin1, crec1, _, y1, bn1 = self.tape[ti - 3]
+        k = 1 if downsample else 0
+        _, xin3, crec3, _, y3, bn3 = self.tape[ti - 1 - k]
+        _, xin2, crec2, _, y2, bn2 = self.tape[ti - 2 - k]
+        _, xin1, crec1, _, y1, bn1 = self.tape[ti - 3 - k]
         x = xin1.act
         self.bwd.tags[len(self.bwd)] = crec3.prefix
         if not out.ginit:
@@ -953,7 +990,17 @@ class Plan(object):
             self.bwd.add(C.OP_GRAD_TERM, ints=(self.dtid, out.N, out.H, out.W, out.C, 0, 0, 0, 0),
                          ptrs=(C.ptr(out.g), C.ptr(out.g), C.ptr(out.t), None, None, None, None, None))
             out.gmasked = True
-        # conv3: dz = d(out) masked (also the identity branch's gradient); its input is relu(bn2(y2))
+        residual = C.ptr(out.g)              # identity: the masked d(out) joins the input gradient of conv1
+        if downsample:
+            _, xind, crecd, _, yd, bnd = self.tape[ti - 1]
+            assert not yd.ginit
+            self.bwd.tags[len(self.bwd)] = crecd.prefix
+            self._bn_bwd_finalize(yd, reduce_from=C.ptr(out.g))
+            self._fused_conv_bwd(C.ptr(out.g), yd, xind, crecd, C.ptr(x.g), None, True, None, lane)
+            yd.ginit = True
+            residual = C.ptr(x.g)            # conv1's launch adds its own input gradient in place
+            self.bwd.tags[len(self.bwd)] = crec3.prefix
+        # conv3: dz = d(out) masked; its input is relu(bn2(y2))
         self._bn_bwd_finalize(y3, reduce_from=C.ptr(out.g))
         self._fused_conv_bwd(C.ptr(out.g), y3, xin3, crec3, C.ptr(y2.g), None, True, y2, lane)
         y2.ginit = y2.gmasked = True
@@ -962,10 +1009,10 @@ class Plan(object):
         self._bn_bwd_finalize(y2, reduce_from=C.ptr(y2.g))
         self._fused_conv_bwd(C.ptr(y2.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane)
         y1.ginit = y1.gmasked = True
-        # conv1: its input is the block input x; the residual stream (the masked d(out)) joins before the mask
+        # conv1: its input is the block input x; the residual stream joins before the mask
         self.bwd.tags[len(self.bwd)] = crec1.prefix
         self._bn_bwd_finalize(y1, reduce_from=C.ptr(y1.g))
-        self._fused_conv_bwd(C.ptr(y1.g), y1, xin1, crec1, C.ptr(x.g), C.ptr(out.g), True,
+        self._fused_conv_bwd(C.ptr(y1.g), y1, xin1, crec1, C.ptr(x.g), residual, True,
                              self._rows_target(x, xin1), lane)
         x.ginit = x.gmasked = True
         if lane == 0 and not in_region:
