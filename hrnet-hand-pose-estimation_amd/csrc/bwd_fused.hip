@@ -37,6 +37,7 @@ struct BwdArgs {
   const char* dz;        // [N,H,W,Cout] upstream gradient w.r.t. the BatchNorm output, ReLU mask applied
   const char* y;         // [N,H,W,Cout] raw conv output
   const float* coef;     // [3][Cout] A,B,C of hrnet_bn_bwd_finalize, or NULL: g = dz
+  HrBnBwdRef ref;        // ref.rows != NULL: the coefficients are built here from the partial rows (coef unused)
   const char* x;         // [N,H,W,Cin] conv input as stored
   const float* in_scale; // optional per-Cin affine (+ReLU) the forward applied on load
   const float* in_shift;
@@ -146,9 +147,15 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 
   FSTAMP();
   // coefficient tables (read back per tile: a dependent global load inside the staging pass costs its full latency)
+  const bool from_rows = a.ref.rows != nullptr;
+  if (from_rows) {
+    static_assert(NT * 2 * 8 <= GBYTES, "row-sum scratch fits the g image");
+    hr_bnbwd_coef_from_rows<NT, COP>(a.ref, a.Cout, (double*)gl, ctab, blockIdx.x == 0);
+  }
   for (int i = tid; i < 3 * COP + 2 * CB; i += NT) {
     float v = 0.f;
     if (i < 3 * COP) {
+      if (from_rows) continue;
       const int w = i / COP, c = i % COP;
       if (a.coef && c < a.Cout) v = a.coef[w * a.Cout + c];
     } else {
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   const int vg = tid % VPG, va = tid % VPA;
   const int cg = vg * VEC, ca = c0 + va * VEC;
   const bool cg_ok = cg < a.Cout, ca_ok = ca < a.Cin;
-  const bool has_coef = a.coef != nullptr, has_aff = a.in_scale != nullptr, in_relu = a.in_relu != 0;
+  const bool has_coef = a.coef != nullptr || from_rows, has_aff = a.in_scale != nullptr, in_relu = a.in_relu != 0;
 
   V16 rz[XG], ry[XG], rx[XA];
   unsigned okg = 0, oka = 0;
@@ -620,16 +627,30 @@ extern "C" int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y,
                                        const float* in_scale, const float* in_shift, int in_relu, const void* wT,
                                        void* dx, const void* addend, int mask_out, float* rows, const void* bs_y,
                                        float* slabs, int N, int H, int W, int Cin, int Cout, hr_stream_t stream) {
+  return hrnet_conv3x3_bwd_fused_bnref(dtype, dz, y, coef, nullptr, x, in_scale, in_shift, in_relu, wT, dx, addend,
+                                       mask_out, rows, bs_y, slabs, N, H, W, Cin, Cout, stream);
+}
+
+extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef,
+                                             const HrBnBwdRef* ref, const void* x, const float* in_scale,
+                                             const float* in_shift, int in_relu, const void* wT, void* dx,
+                                             const void* addend, int mask_out, float* rows, const void* bs_y,
+                                             float* slabs, int N, int H, int W, int Cin, int Cout,
+                                             hr_stream_t stream) {
   HR_REQUIRE(hrnet_bwd_fused_supported(dtype, Cin, Cout), "bwd_fused: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
   HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_fused: null pointer");
-  HR_REQUIRE(!coef || y, "bwd_fused: coef needs y");
+  HR_REQUIRE((!coef && !ref) || y, "bwd_fused: coef needs y");
+  HR_REQUIRE(!ref || (ref->rows && ref->gamma && ref->save_mean && ref->save_invstd && ref->dgamma && ref->dbeta &&
+                      ref->nrows >= 1 && (long long)ref->nrows * Cout <= 16384 && ref->count > 0.f),
+             "bwd_fused: incomplete HrBnBwdRef (or nrows * Cout > 16384)");
   HR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "bwd_fused: scale/shift must come together");
   HR_REQUIRE(!bs_y || rows, "bwd_fused: bs_y needs rows");
   HR_REQUIRE(N > 0 && H > 0 && W > 0, "bwd_fused: empty shape");
   HR_REQUIRE((double)H * W * (Cin > Cout ? Cin : Cout) * 4.0 < 2147483648.0, "bwd_fused: one image exceeds 2 GiB");
   const FusedCfg c = fused_cfg(dtype, Cout);
   BwdArgs a;
-  a.dz = (const char*)dz; a.y = (const char*)y; a.coef = coef; a.x = (const char*)x;
+  a.dz = (const char*)dz; a.y = (const char*)y; a.coef = ref ? nullptr : coef; a.x = (const char*)x;
+  if (ref) a.ref = *ref; else a.ref = HrBnBwdRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, 0};
   a.in_scale = in_scale; a.in_shift = in_shift; a.wT = (const char*)wT; a.dx = (char*)dx;
   a.addend = (const char*)addend; a.bs_y = (const char*)bs_y; a.rows = rows; a.slabs = slabs;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -654,7 +675,9 @@ extern "C" int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y,
 }
 
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s) {
-  return hrnet_conv3x3_bwd_fused(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4],
-                                 (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7], (float*)op.p[9],
-                                 op.p[10], (float*)op.p[11], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL
+  return hrnet_conv3x3_bwd_fused_bnref(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12],
+                                       op.p[3], (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7],
+                                       op.p[8], op.i[7], (float*)op.p[9], op.p[10], (float*)op.p[11], op.i[1], op.i[2],
+                                       op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
 }

@@ -27,6 +27,7 @@ struct PwArgs {
   const char* dz;        // [P,Cout] upstream gradient w.r.t. the BatchNorm output, ReLU mask applied
   const char* y;         // [P,Cout] raw conv output
   const float* coef;     // [3][Cout] A,B,C of hrnet_bn_bwd_finalize, or NULL: g = dz
+  HrBnBwdRef ref;        // ref.rows != NULL: the coefficients are built here from the partial rows (coef unused)
   const char* x;         // [P,Cin] conv input as stored
   const float* in_scale; // optional per-Cin affine (+ReLU) the forward applied on load
   const float* in_shift;
@@ -87,19 +88,29 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
   }
   // a thread keeps one channel vector of each side for every tile: its coefficients live in registers
   const int vg = tid % VPG, va = tid % VPA;
-  const bool has_coef = a.coef != nullptr, has_aff = AFF && a.in_scale != nullptr, in_relu = a.in_relu != 0;
+  const bool from_rows = a.ref.rows != nullptr;
+  const bool has_coef = a.coef != nullptr || from_rows, has_aff = AFF && a.in_scale != nullptr, in_relu = a.in_relu != 0;
   float cA[VEC], cB[VEC], cC[VEC], sc[AFF ? VEC : 1], sh[AFF ? VEC : 1];
+  const float* ctab = a.coef;
+  if (from_rows) {
+    // scratch and table live in the (still unused) tile region; the helper ends with a barrier
+    static_assert(NT * 2 * 8 + 3 * CO * 4 <= GBYTES + ABYTES, "row-sum scratch fits the tiles");
+    float* tab = (float*)(lds + NT * 2 * 8);
+    hr_bnbwd_coef_from_rows<NT, CO>(a.ref, CO, (double*)lds, tab, blockIdx.x == 0);
+    ctab = tab;
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    cA[j] = has_coef ? a.coef[vg * VEC + j] : 1.f;
-    cB[j] = has_coef ? a.coef[CO + vg * VEC + j] : 0.f;
-    cC[j] = has_coef ? a.coef[2 * CO + vg * VEC + j] : 0.f;
+    cA[j] = has_coef ? ctab[vg * VEC + j] : 1.f;
+    cB[j] = has_coef ? ctab[CO + vg * VEC + j] : 0.f;
+    cC[j] = has_coef ? ctab[2 * CO + vg * VEC + j] : 0.f;
     if constexpr (AFF) {
       sc[j] = has_aff ? a.in_scale[va * VEC + j] : 1.f;
       sh[j] = has_aff ? a.in_shift[va * VEC + j] : 0.f;
     }
   }
 
+  if (from_rows) __syncthreads();   // every thread has its coefficients: the table's LDS becomes tile space
   // weight gradient: this wave's co fragments x ci fragments; D: col (li) = ci, rows (lg*4+r) = co
   const int wco = wave % COSPLIT, wci = wave / COSPLIT;
   f32x4 accw[FCOW][FCIW];
@@ -330,16 +341,29 @@ extern "C" int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y,
                                        const float* in_scale, const float* in_shift, int in_relu, const void* wT,
                                        void* dx, const void* addend, int mask_out, float* rows, const void* bs_y,
                                        float* slabs, long long pixels, int Cin, int Cout, hr_stream_t stream) {
+  return hrnet_conv1x1_bwd_fused_bnref(dtype, dz, y, coef, nullptr, x, in_scale, in_shift, in_relu, wT, dx, addend,
+                                       mask_out, rows, bs_y, slabs, pixels, Cin, Cout, stream);
+}
+
+extern "C" int hrnet_conv1x1_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef,
+                                             const HrBnBwdRef* ref, const void* x, const float* in_scale,
+                                             const float* in_shift, int in_relu, const void* wT, void* dx,
+                                             const void* addend, int mask_out, float* rows, const void* bs_y,
+                                             float* slabs, long long pixels, int Cin, int Cout, hr_stream_t stream) {
   HR_REQUIRE(hrnet_bwd_pw_supported(dtype, Cin, Cout), "bwd_pw: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
   HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_pw: null pointer");
-  HR_REQUIRE(!coef || y, "bwd_pw: coef needs y");
+  HR_REQUIRE((!coef && !ref) || y, "bwd_pw: coef needs y");
+  HR_REQUIRE(!ref || (ref->rows && ref->gamma && ref->save_mean && ref->save_invstd && ref->dgamma && ref->dbeta &&
+                      ref->nrows >= 1 && (long long)ref->nrows * Cout <= 8192 && ref->count > 0.f),
+             "bwd_pw: incomplete HrBnBwdRef (or nrows * Cout > 8192)");
   HR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "bwd_pw: scale/shift must come together");
   HR_REQUIRE(!bs_y || rows, "bwd_pw: bs_y needs rows");
   HR_REQUIRE(!in_scale || Cin <= 64, "bwd_pw: no input affine for Cin %d", Cin);
   HR_REQUIRE(!rows || hrnet_bwd_pw_rows_supported(dtype, Cin, Cout), "bwd_pw: no statistics rows for Cin %d", Cin);
   HR_REQUIRE(pixels > 0 && pixels < (1ll << 31) * 64, "bwd_pw: pixel count");
   PwArgs a;
-  a.dz = (const char*)dz; a.y = (const char*)y; a.coef = coef; a.x = (const char*)x;
+  a.dz = (const char*)dz; a.y = (const char*)y; a.coef = ref ? nullptr : coef; a.x = (const char*)x;
+  if (ref) a.ref = *ref; else a.ref = HrBnBwdRef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, 0};
   a.in_scale = in_scale; a.in_shift = in_shift; a.wT = (const char*)wT; a.dx = (char*)dx;
   a.addend = (const char*)addend; a.bs_y = (const char*)bs_y; a.rows = rows; a.slabs = slabs;
   a.P = pixels;
@@ -358,8 +382,9 @@ extern "C" int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y,
 // op slots as OP_BWD_FUSED (p[0..11] = dz,y,coef,x,scale,shift,wT,dx,addend,rows,bs_y,slabs;
 // i[0..7] = dtype,N,H,W,Cin,Cout,in_relu,mask_out)
 int hr_launch_bwd_pw(const HrOp& op, hipStream_t s) {
-  return hrnet_conv1x1_bwd_fused(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4],
-                                 (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7], (float*)op.p[9],
-                                 op.p[10], (float*)op.p[11], (long long)op.i[1] * op.i[2] * op.i[3], op.i[4], op.i[5],
-                                 (hr_stream_t)s);
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL
+  return hrnet_conv1x1_bwd_fused_bnref(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12],
+                                       op.p[3], (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7],
+                                       op.p[8], op.i[7], (float*)op.p[9], op.p[10], (float*)op.p[11],
+                                       (long long)op.i[1] * op.i[2] * op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
 }

@@ -131,6 +131,50 @@ __device__ __forceinline__ void hr_bn_from_sums(const float* sums, int C, int c,
   shift = beta - mean * scale;
 }
 
+// BatchNorm-backward coefficients built by the consuming workgroup from the partial rows a previous launch left
+// (HrBnBwdRef): thread t sums rows t/CP, t/CP + NT/CP, ... of channel t%CP in f64, the row groups are added in a
+// fixed order, then A,B,C as hrnet_bn_bwd_finalize computes them. `scratch`: NT*2 doubles of LDS; `tab`: [3][CP]
+// floats of LDS. Ends with a barrier: tab is readable, scratch is free. `writer`: this workgroup stores dgamma/dbeta.
+template <int NT, int CP>
+__device__ __forceinline__ void hr_bnbwd_coef_from_rows(const HrBnBwdRef& r, int C, double* scratch, float* tab,
+                                                        bool writer) {
+  static_assert(NT % CP == 0, "row groups");
+  constexpr int NRG = NT / CP;
+  const int tid = threadIdx.x, c = tid % CP, rg = tid / CP;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int t = rg; t < r.nrows; t += NRG) {
+      a += (double)r.rows[((size_t)t * 2 + 0) * C + c];
+      b += (double)r.rows[((size_t)t * 2 + 1) * C + c];
+    }
+  scratch[(rg * 2 + 0) * CP + c] = a;
+  scratch[(rg * 2 + 1) * CP + c] = b;
+  __syncthreads();
+  if (tid < CP) {
+    float A = 0.f, B = 0.f, Cc = 0.f;
+    if (c < C) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < NRG; ++q) {
+        s1 += scratch[(q * 2 + 0) * CP + c];
+        s2 += scratch[(q * 2 + 1) * CP + c];
+      }
+      const double mu = r.save_mean[c], iv = r.save_invstd[c], g = r.gamma[c], n = (double)r.count;
+      const double dg = iv * (s2 - mu * s1);   // sum dz * xhat
+      if (writer) {
+        r.dgamma[c] = r.accumulate ? r.dgamma[c] + (float)dg : (float)dg;
+        r.dbeta[c] = r.accumulate ? r.dbeta[c] + (float)s1 : (float)s1;
+      }
+      A = (float)(g * iv);
+      B = (float)(-g * iv * iv * dg / n);
+      Cc = (float)(-g * iv * s1 / n + g * iv * iv * mu * dg / n);
+    }
+    tab[c] = A;
+    tab[CP + c] = B;
+    tab[2 * CP + c] = Cc;
+  }
+  __syncthreads();
+}
+
 // host-side error plumbing (api.hip)
 void hr_set_error(const char* fmt, ...);
 int hr_check_launch(const char* what);

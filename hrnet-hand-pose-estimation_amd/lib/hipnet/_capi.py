@@ -49,6 +49,13 @@ class HrBnEnt(ctypes.Structure):
                 ('reserved', ctypes.c_int32)]
 
 
+class HrBnBwdRef(ctypes.Structure):
+    _fields_ = [('rows', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('save_mean', ctypes.c_void_p),
+                ('save_invstd', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+                ('count', ctypes.c_float), ('nrows', ctypes.c_int32), ('accumulate', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 _c_int, _c_float, _c_vp, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 _pp = ctypes.POINTER(ctypes.c_void_p)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -72,6 +79,8 @@ _SIGS = {
     'hrnet_wgrad_kernel_name': [_c_int] * 7 + [ctypes.c_char_p, _c_int],
     'hrnet_conv2d_wgrad': [_c_int] + [_c_vp] * 5 + [_c_int] * 11 + [_c_vp],
     'hrnet_conv3x3_bwd_fused': [_c_int] + [_c_vp] * 6 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp],
+    'hrnet_conv3x3_bwd_fused_bnref': [_c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_vp],
+    'hrnet_conv1x1_bwd_fused_bnref': [_c_int] + [_c_vp] * 7 + [_c_int] + [_c_vp] * 3 + [_c_int] + [_c_vp] * 3 + [_c_i64, _c_int, _c_int] + [_c_vp],
     'hrnet_bwd_fused_supported': [_c_int] * 3,
     'hrnet_bwd_fused_splits': [_c_int] * 6,
     'hrnet_bwd_fused_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],

@@ -603,6 +603,8 @@ class Plan(object):
         self.slab_bytes = 0
         fuse_stats = self.training and os.environ.get('HRNET_FUSE_BWDSTATS', '1') != '0'
         self.n_fused_bwdstats = 0
+        self._bnrefs = []
+        self.n_inline_bnbwd = 0
         self.inter_gop = None
         in_region = False
         self._producer_sum = producer_sum
@@ -924,12 +926,30 @@ class Plan(object):
             self._scratch(self.bwd, j, 0, 'bwdpart')
         y.bn_done = True
 
-    def _fused_conv_bwd(self, dz, y, xin, crec, dx, addend, mask_out, rows_for, lane):
+    def _fused_conv_bwd(self, dz, y, xin, crec, dx, addend, mask_out, rows_for, lane, reduce_from=None):
         """one hrnet_conv3x3_bwd_fused / hrnet_conv1x1_bwd_fused launch: backward of `y = conv(xin)` given the masked
         gradient `dz` of y's BatchNorm output; writes the gradient of xin's activation into `dx` and y's
-        weight-gradient slabs. rows_for: the raw activation whose BatchNorm-backward sums the launch gathers."""
+        weight-gradient slabs. rows_for: the raw activation whose BatchNorm-backward sums the launch gathers.
+        The BatchNorm backward of y itself is finished first: by the launch (from the partial rows a previous
+        launch left: HrBnBwdRef, no finalize launch in between) when there are few enough rows, else by
+        _bn_bwd_finalize (rows, or a reduction pass over `reduce_from`)."""
         net, x = self.net, xin.act
         ks = crec.ks
+        ref = None
+        lim = 16384 if ks == 3 else 8192
+        if (y.bwd_rows is not None and y.bwd_rows[1] * y.C <= lim
+                and os.environ.get('HRNET_BNBWD_INLINE', '1') != '0'):
+            b, m = y.bn, y.bn.mod
+            ref = C.HrBnBwdRef()
+            ref.rows, ref.gamma = C.ptr(y.bwd_rows[0]), C.ptr(m.weight)
+            ref.save_mean, ref.save_invstd = C.ptr(b.mean), C.ptr(b.invstd)
+            ref.dgamma, ref.dbeta = C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias))
+            ref.count, ref.nrows, ref.accumulate = float(y.pixels), int(y.bwd_rows[1]), 1
+            self._bnrefs.append(ref)             # host structs the recorded op points at
+            self.n_inline_bnbwd += 1
+            y.bn_done = True
+        else:
+            self._bn_bwd_finalize(y, reduce_from=reduce_from)
         if ks == 3:
             ns = C.call('hrnet_bwd_fused_splits', self.dtid, x.N, x.H, x.W, x.C, y.C)
             kind = C.OP_BWD_FUSED
@@ -947,10 +967,11 @@ class Plan(object):
             self.n_fused_bwdstats += 1
         self.bwd.add(kind,
                      ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0),
-                     ptrs=(dz, C.ptr(y.t), C.ptr(y.bn.coef), C.ptr(x.t),
+                     ptrs=(dz, C.ptr(y.t), None if ref is not None else C.ptr(y.bn.coef), C.ptr(x.t),
                            C.ptr(xin.bn.scale) if xin.bn else None, C.ptr(xin.bn.shift) if xin.bn else None,
                            C.ptr(crec.wd), dx, addend, C.ptr(rows),
-                           C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs)))
+                           C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs),
+                           ctypes.addressof(ref) if ref is not None else None))
         w = crec.mod.weight
         ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
                    Cout=crec.Cout, Cin=crec.Cin, kflat=0, accumulate=1)
@@ -995,25 +1016,24 @@ class Plan(object):
             _, xind, crecd, _, yd, bnd = self.tape[ti - 1]
             assert not yd.ginit
             self.bwd.tags[len(self.bwd)] = crecd.prefix
-            self._bn_bwd_finalize(yd, reduce_from=C.ptr(out.g))
-            self._fused_conv_bwd(C.ptr(out.g), yd, xind, crecd, C.ptr(x.g), None, True, None, lane)
+            self._fused_conv_bwd(C.ptr(out.g), yd, xind, crecd, C.ptr(x.g), None, True, None, lane,
+                                 reduce_from=C.ptr(out.g))
             yd.ginit = True
             residual = C.ptr(x.g)            # conv1's launch adds its own input gradient in place
             self.bwd.tags[len(self.bwd)] = crec3.prefix
         # conv3: dz = d(out) masked; its input is relu(bn2(y2))
-        self._bn_bwd_finalize(y3, reduce_from=C.ptr(out.g))
-        self._fused_conv_bwd(C.ptr(out.g), y3, xin3, crec3, C.ptr(y2.g), None, True, y2, lane)
+        self._fused_conv_bwd(C.ptr(out.g), y3, xin3, crec3, C.ptr(y2.g), None, True, y2, lane,
+                             reduce_from=C.ptr(out.g))
         y2.ginit = y2.gmasked = True
         y3.ginit = True
         self.bwd.tags[len(self.bwd)] = crec2.prefix
-        self._bn_bwd_finalize(y2, reduce_from=C.ptr(y2.g))
-        self._fused_conv_bwd(C.ptr(y2.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane)
+        self._fused_conv_bwd(C.ptr(y2.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane,
+                             reduce_from=C.ptr(y2.g))
         y1.ginit = y1.gmasked = True
         # conv1: its input is the block input x; the residual stream joins before the mask
         self.bwd.tags[len(self.bwd)] = crec1.prefix
-        self._bn_bwd_finalize(y1, reduce_from=C.ptr(y1.g))
         self._fused_conv_bwd(C.ptr(y1.g), y1, xin1, crec1, C.ptr(x.g), residual, True,
-                             self._rows_target(x, xin1), lane)
+                             self._rows_target(x, xin1), lane, reduce_from=C.ptr(y1.g))
         x.ginit = x.gmasked = True
         if lane == 0 and not in_region:
             self._bucket_mark_after_conv(crec1)
@@ -1033,12 +1053,11 @@ class Plan(object):
                          ptrs=(C.ptr(out.g), C.ptr(out.g), C.ptr(out.t), None, None, None, None, None))
             out.gmasked = True
         # conv2: dz = d(out) masked (it is also the identity branch's gradient); its input is relu(bn1(y1))
-        self._bn_bwd_finalize(y2, reduce_from=C.ptr(out.g))
-        self._fused_conv_bwd(C.ptr(out.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane)
+        self._fused_conv_bwd(C.ptr(out.g), y2, xin2, crec2, C.ptr(y1.g), None, True, y1, lane,
+                             reduce_from=C.ptr(out.g))
         y1.ginit = y1.gmasked = True
         y2.ginit = True
         # conv1: its input is the block input x; the residual stream (the masked d(out)) joins before the mask
-        self._bn_bwd_finalize(y1)
         target = None
         if x is not self.inter_act:
             if xin1.bn is not None:

@@ -179,6 +179,29 @@ int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y, const floa
                             const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs, int N,
                             int H, int W, int Cin, int Cout, hr_stream_t stream);
 int hrnet_bwd_fused_supported(int dtype, int Cin, int Cout);
+/*
+ * The fused launches can finish the BatchNorm backward of their own output themselves: instead of `coef` (written by
+ * a hrnet_bn_bwd_finalize launch in between) they take the partial rows [nrows][2][Cout] the previous launch left
+ * - every workgroup sums them in a fixed order (f64) and builds A,B,C itself; the first workgroup also adds
+ * dgamma / dbeta. Same arithmetic as hrnet_bn_bwd_finalize, deterministic, one launch and one dependency less per
+ * BatchNorm. `ref` is a HOST struct copied into the launch; NULL = use `coef`. Keep nrows * Cout <= 16384
+ * (3x3) / 8192 (1x1): every workgroup reads all rows.
+ */
+typedef struct HrBnBwdRef {
+  const float* rows;    /* [nrows][2][Cout]: (sum dz, sum dz*y) partials */
+  const float* gamma;
+  const float* save_mean;
+  const float* save_invstd;
+  float* dgamma;        /* += (accumulate) or = */
+  float* dbeta;
+  float count;          /* elements per channel */
+  int32_t nrows, accumulate, reserved;
+} HrBnBwdRef;
+int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                                  const void* x, const float* in_scale, const float* in_shift, int in_relu,
+                                  const void* wT, void* dx, const void* addend, int mask_out, float* rows,
+                                  const void* bs_y, float* slabs, int N, int H, int W, int Cin, int Cout,
+                                  hr_stream_t stream);
 int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, int Cout);
 int hrnet_bwd_fused_kernel_name(int dtype, int Cin, int Cout, char* buf, int buflen);
 
@@ -195,6 +218,11 @@ int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y, const floa
                             const float* in_scale, const float* in_shift, int in_relu, const void* wT, void* dx,
                             const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
                             long long pixels, int Cin, int Cout, hr_stream_t stream);
+int hrnet_conv1x1_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                                  const void* x, const float* in_scale, const float* in_shift, int in_relu,
+                                  const void* wT, void* dx, const void* addend, int mask_out, float* rows,
+                                  const void* bs_y, float* slabs, long long pixels, int Cin, int Cout,
+                                  hr_stream_t stream);
 int hrnet_bwd_pw_supported(int dtype, int Cin, int Cout);
 int hrnet_bwd_pw_rows_supported(int dtype, int Cin, int Cout);
 int hrnet_bwd_pw_splits(int dtype, long long pixels, int Cin, int Cout);

@@ -370,16 +370,17 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
                         continue
                     if int(o32.kind) in (C.OP_CONV, C.OP_BWD_FUSED):
                         # backward-statistics rows (sum dz, sum dz*y per channel): compared as vectors over the
-                        # channels, NOT replaced - the finalize op that follows consumes the bf16 path's own sums.
+                        # channels, then replaced like every other output (the consumer - a finalize op, or the next
+                        # fused launch, which builds its coefficients from the rows itself - sees exact sums).
                         # Many of these sums cancel structurally (the gradient behind a BatchNorm sums to zero per
                         # channel; what is left are border and ReLU-mask terms), so the 2^-9 rounding of the inputs
-                        # is large against them: they are held to a loose band, their effect - the BatchNorm
-                        # backward output that the next grad_term op writes - to the tight one.
+                        # is large against them: they are held to a loose band.
                         c = p32.acts[a32[o32.p[5] if int(o32.kind) == C.OP_CONV else o32.p[7]][1]].C
                         s32, s16 = v32.view(-1, 2, c).double().sum(0), v16.view(-1, 2, c).double().sum(0)
                         for w in range(2):
                             stat_errs.append(((s32[w] - s16[w]).norm().item() / max(s32[w].norm().item(), 1e-30),
                                               int(o32.kind), k, 'sum dz' + ('*y' if w else '') + ' behind op {}'.format(k)))
+                        v16.copy_(v32)
                         continue
                 d = (v16.float() - v32).double().norm().item()
                 n = v32.double().norm().item()
@@ -418,7 +419,7 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
     ge_w = report(ge_w, 'conv weight gradients')
     ge_b = report(ge_b, 'BatchNorm / bias gradients (per-channel sums)')
     assert (hm16 - hm32).norm().item() <= 1e-2 * hm32.norm().item()
-    assert len(fe) >= 400 and len(be) >= (900 if fused == 'unfused' else 700) and len(ge_w) >= 300
+    assert len(fe) >= 400 and len(be) >= (900 if fused == 'unfused' else 600) and len(ge_w) >= 300
     # bf16 operands (2^-9 relative rounding of inputs, weights and the stored result), f32 accumulation.
     # Measured (MI355X): forward median 1.6e-3 / worst 4.3e-3; backward median 2.4e-3; conv weight gradients
     # p99 4.4e-3; per-channel sums up to 5e-2 where the sum cancels (see above).

@@ -135,3 +135,69 @@ def test_fused_backward_in_place_on_the_residual_stream():
            None, None, 0, wT.data_ptr(), buf.data_ptr(), buf.data_ptr(), 1, None, None, slabs.data_ptr(), N, H, W, Cc, Cc,
            C.stream_ptr())
     assert hh.rel_err(hh.from_nhwc(buf), want) <= 4e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32, 32, 128, 3), (3, 20, 24, 64, 64, 64, 3), (2, 16, 16, 64, 256, 7, 1),
+                                   (2, 16, 16, 256, 64, 128, 1), (2, 16, 16, 64, 64, 1, 1)])
+def test_fused_launch_finishes_its_own_batchnorm_backward_from_rows(dtype, shape):
+    """HrBnBwdRef: the launch builds A,B,C from the partial rows a previous launch left and adds dgamma/dbeta -
+    same outputs as hrnet_bn_bwd_finalize followed by the launch with `coef` (bit-identical gradients: the
+    coefficients are computed by the same f64 formula; only the order of the row sum differs)"""
+    import ctypes
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cin, Cout, nrows, ks = shape
+    dt = hh.dt_id(dtype)
+    if ks == 3 and not C.call('hrnet_bwd_fused_supported', dt, Cin, Cout):
+        pytest.skip('shape served by the unfused kernels in fp32')
+    if ks == 1 and not C.call('hrnet_bwd_pw_supported', dt, Cin, Cout):
+        pytest.skip('the pointwise fused backward is bf16 only')
+    g = torch.Generator().manual_seed(11 + Cin + Cout + nrows)
+    d = hh.DEV
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks), dtype)
+    x, dz, y = (_q(torch.randn(N, c, H, W, generator=g), dtype) for c in (Cin, Cout, Cout))
+    wT, _, _ = hh.pack_weights(w, dtype, mode=1)
+    xd, dzd, yd = (hh.nhwc(t, dtype) for t in (x, dz, y))
+    rows_in = torch.randn(nrows, 2, Cout, generator=g).to(d)
+    gamma, mean = (torch.rand(Cout, generator=g) + 0.5).to(d), torch.randn(Cout, generator=g).to(d)
+    invstd = (torch.rand(Cout, generator=g) + 0.5).to(d)
+    count = float(N * H * W)
+    P = N * H * W
+    if ks == 3:
+        ns = C.call('hrnet_bwd_fused_splits', dt, N, H, W, Cin, Cout)
+    else:
+        ns = C.call('hrnet_bwd_pw_splits', dt, P, Cin, Cout)
+    outs = []
+    for mode in ('finalize', 'inline'):
+        dgam, dbet = torch.full((Cout,), 0.25, device=d), torch.full((Cout,), -0.5, device=d)   # accumulate into these
+        coef = torch.zeros(3 * Cout, device=d)
+        slabs = torch.zeros(ns, Cout, ks * ks, Cin, device=d)
+        dx = torch.zeros(N, H, W, Cin, dtype=dtype, device=d)
+        ref = None
+        if mode == 'finalize':
+            C.call('hrnet_bn_bwd_finalize', rows_in.data_ptr(), nrows, Cout, count, gamma.data_ptr(), mean.data_ptr(),
+                   invstd.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), 1, C.stream_ptr())
+        else:
+            ref = C.HrBnBwdRef()
+            ref.rows, ref.gamma, ref.save_mean, ref.save_invstd = (t.data_ptr() for t in (rows_in, gamma, mean, invstd))
+            ref.dgamma, ref.dbeta, ref.count, ref.nrows, ref.accumulate = dgam.data_ptr(), dbet.data_ptr(), count, nrows, 1
+        rp = ctypes.addressof(ref) if ref is not None else None
+        cp = coef.data_ptr() if ref is None else None
+        if ks == 3:
+            C.call('hrnet_conv3x3_bwd_fused_bnref', dt, dzd.data_ptr(), yd.data_ptr(), cp, rp, xd.data_ptr(), None, None, 0,
+                   wT.data_ptr(), dx.data_ptr(), None, 1, None, None, slabs.data_ptr(), N, H, W, Cin, Cout, C.stream_ptr())
+        else:
+            C.call('hrnet_conv1x1_bwd_fused_bnref', dt, dzd.data_ptr(), yd.data_ptr(), cp, rp, xd.data_ptr(), None, None, 0,
+                   wT.data_ptr(), dx.data_ptr(), None, 1, None, None, slabs.data_ptr(), P, Cin, Cout, C.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((dx.float().cpu(), slabs.sum(0).cpu(), dgam.cpu(), dbet.cpu()))
+    (dx_f, gw_f, dg_f, db_f), (dx_i, gw_i, dg_i, db_i) = outs
+    assert dx_f.abs().max() > 0
+    # dgamma/dbeta: f64 sums in another order, rounded to f32 once
+    np.testing.assert_allclose(dg_i.numpy(), dg_f.numpy(), rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(db_i.numpy(), db_f.numpy(), rtol=2e-6, atol=1e-5)
+    # the coefficients may differ in the last f32 bit -> the bf16-rounded g in a few places
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert hh.rel_err(dx_i, dx_f) <= tol
+    assert hh.rel_err(gw_i, gw_f) <= tol
