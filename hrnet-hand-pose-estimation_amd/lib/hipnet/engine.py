@@ -617,6 +617,7 @@ class Plan(object):
         dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not dp and not self.wlane
                             and os.environ.get('HRNET_DEFER_WGRAD', '1') != '0')
+        self.defer_branch_wgrads = os.environ.get('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
         self._deferred = []
         self._deferred_lanes = []
         self.n_deferred_wgrads = 0
@@ -727,7 +728,8 @@ class Plan(object):
                     self.bwd.lane = self.wlane
                 nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
                 deferred = (self.batch_wred and self.defer_wgrad and in_region and first_fork is not None
-                            and ti > first_fork)
+                            and ti > first_fork
+                            and (self.defer_branch_wgrads or '.branches.' not in crec.prefix))
                 if deferred and nsplit > 1:
                     # A deferred launch runs in the background of the single-lane tail: it does not need the
                     # parallelism of many splits, and every split is a slab written and read back.
