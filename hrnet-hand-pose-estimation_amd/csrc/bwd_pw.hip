@@ -9,7 +9,7 @@
 //   dW[co,ci] += sum_p g[p,co] * a[p,ci]                    weight gradient (pixels = K, transposing LDS reads)
 //   v[p,ci]  = sum_co Wt[ci,co] * g[p,co] (+ addend[p,ci])  input gradient (+ the residual stream)
 //   dx[p,ci] = v * [a[p,ci] > 0]                            masked by the ReLU in front of the conv
-//   rows     = (sum dx, sum dx*yb)                          statistics of the next BatchNorm backward (Cin <= 64)
+//   rows     = (sum dx, sum dx*yb)                          statistics of the next BatchNorm backward
 //
 // The kernel is an HBM stream (17 GFLOP against 330-470 MB per launch at batch 64): 64-pixel tiles, 4 waves,
 // ~78 KB of LDS (g tile, a tile, the whole weight matrix resident) so that TWO workgroups share a CU - one
@@ -54,8 +54,10 @@ __device__ __forceinline__ V16 trl16(const char* base, int r0, int rstep, int ch
   return __builtin_bit_cast(V16, v);
 }
 
+// (the 256-channel input side keeps 64 + 64 accumulator registers, the residual and statistics operands: one
+// wave per SIMD with the full register file; it is launched one workgroup per CU)
 template <int CO, int CI>
-__global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8, ES = 2, NT = 256, TP = 64;
   constexpr int GPIX = CO * ES + 16, APIX = CI * ES + 16, WROW = CO * ES + 16;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
   constexpr int COSPLIT = CO == 256 ? 4 : 1, CISPLIT = 4 / COSPLIT;
   constexpr int FCOW = FCO / COSPLIT, FCIW = FCI / CISPLIT;     // weight-gradient fragments per wave
   constexpr bool ROWS = CI <= 64;                               // statistics in registers: 2 x CI/4 per lane
+  constexpr bool ROWS2 = !ROWS;                                 // 256 channels: through the LDS tile, per staging thread
   constexpr bool AFF = CI <= 64;                                // input affine (a 256-channel input is a stored activation)
   static_assert(TP * VPG % NT == 0 && TP * VPA % NT == 0 && FCO % COSPLIT == 0 && FCI % CISPLIT == 0, "geometry");
   static_assert(GBYTES + ABYTES + WBYTES <= 80 * 1024, "two workgroups per CU");
@@ -121,6 +124,13 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
   float s1[ROWS ? NG * 8 : 1], s2[ROWS ? NG * 8 : 1];
 #pragma unroll
   for (int k = 0; k < (ROWS ? NG * 8 : 1); ++k) s1[k] = s2[k] = 0.f;
+  // wide input side: the MFMA layout gives a lane 8 channels of EVERY 32-channel group (128 partial sums), so the
+  // masked result goes back into the input tile's LDS (each lane overwrites exactly the mask values it read) and
+  // the statistics are taken in the staging layout, where a thread keeps ONE channel vector: 16 sums per thread
+  float t1[ROWS2 ? VEC : 1], t2[ROWS2 ? VEC : 1];
+#pragma unroll
+  for (int k = 0; k < (ROWS2 ? VEC : 1); ++k) t1[k] = t2[k] = 0.f;
+  const bool rows2 = ROWS2 && a.rows != nullptr;
 
   // input gradient D[ci][pixel]: a wave owns 16 pixels x all CI channels
   const int boff = (wave * 16 + li) * GPIX + lg * 16;
@@ -222,6 +232,16 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
     }
 
     // ---- tile epilogue: residual addend, ReLU mask from the staged input tile, store, statistics ----
+    V16 qb[ROWS2 ? XA : 1];
+    if constexpr (ROWS2) {
+      if (rows2 && a.bs_y) {
+#pragma unroll
+        for (int k = 0; k < XA; ++k) {
+          const long long p = p0 + tid / VPA + k * PSA;
+          qb[k] = *(const V16*)(a.bs_y + (p < a.P ? ((size_t)p * CI + va * VEC) * ES : 0));
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       float v[8];
@@ -240,7 +260,11 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = am[k] > 0.f ? v[k] : 0.f;
         }
-        *(V16*)(a.dx + eo + j * 32 * ES) = v16_pack<T>(v);
+        const V16 packed = v16_pack<T>(v);
+        *(V16*)(a.dx + eo + j * 32 * ES) = packed;
+        if constexpr (ROWS2) {
+          if (rows2) *(V16*)(al + (wave * 16 + li) * APIX + (j * 32 + lg * 8) * ES) = packed;
+        }
         if constexpr (ROWS) {
           if (a.rows) {
             float yb[8];
@@ -251,6 +275,27 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
               s2[j * 8 + k] = fmaf(v[k], yb[k], s2[j * 8 + k]);
             }
           }
+        }
+      } else {
+        if constexpr (ROWS2) {
+          if (rows2) *(V16*)(al + (wave * 16 + li) * APIX + (j * 32 + lg * 8) * ES) = v16_zero();
+        }
+      }
+    }
+    if constexpr (ROWS2) {
+      if (rows2) {
+        __syncthreads();   // the input tile now holds the stored gradient
+#pragma unroll
+        for (int k = 0; k < XA; ++k) {
+          float dv[VEC], yb[VEC];
+          v16_unpack<T>(*(const V16*)(al + (tid / VPA + k * PSA) * APIX + va * 16), dv);
+          if (a.bs_y) {
+            v16_unpack<T>(qb[k], yb);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) t2[j] = fmaf(dv[j], yb[j], t2[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) t1[j] += dv[j];
         }
       }
     }
@@ -286,6 +331,26 @@ __global__ __launch_bounds__(256, 2) void bwd_pw_kernel(PwArgs a) {
     }
   }
 
+  if constexpr (ROWS2) {
+    if (rows2) {
+      float* sl = (float*)lds;   // [NT / VPA thread groups][2][CI]
+      constexpr int NGRP = NT / VPA;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        sl[((tid / VPA) * 2 + 0) * CI + va * VEC + j] = t1[j];
+        sl[((tid / VPA) * 2 + 1) * CI + va * VEC + j] = t2[j];
+      }
+      __syncthreads();
+      for (int o = tid; o < 2 * CI; o += NT) {
+        const int which = o / CI, cl = o % CI;
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) sacc += sl[(q * 2 + which) * CI + cl];
+        a.rows[((size_t)split * 2 + which) * CI + cl] = sacc;
+      }
+    }
+  }
+
   // ---- weight-gradient slab of this workgroup: slab[split][co][ci] ----
   float* slab = a.slabs + (size_t)split * CO * CI;
 #pragma unroll
@@ -313,9 +378,10 @@ extern "C" int hrnet_bwd_pw_supported(int dtype, int Cin, int Cout) {
   return dtype == HR_BF16 && pw_shape(Cin, Cout) != 0 ? 1 : 0;
 }
 
-// 1 if the launch can also gather the next BatchNorm's backward sums (`rows`): input side of at most 64 channels
+// 1 if the launch can also gather the next BatchNorm's backward sums (`rows`): every served shape (the wide
+// input side takes them through LDS)
 extern "C" int hrnet_bwd_pw_rows_supported(int dtype, int Cin, int Cout) {
-  return hrnet_bwd_pw_supported(dtype, Cin, Cout) && Cin <= 64 ? 1 : 0;
+  return hrnet_bwd_pw_supported(dtype, Cin, Cout);
 }
 
 // number of slabs / statistics rows = workgroups, every one walking the same number of 64-pixel tiles when

@@ -211,8 +211,7 @@ int hrnet_bwd_fused_kernel_name(int dtype, int Cin, int Cout, char* buf, int buf
  * bs_y [pixels,Cin]; wT = hrnet_pack_weights(mode 1) of the 1x1 kernel ([Cin][Cout]); slabs
  * [hrnet_bwd_pw_splits()][Cout][Cin] f32 (sum with hrnet_wgrad_reduce, ks = 1). bf16 only; served shapes
  * (Cin,Cout) = (64,256), (256,64), (64,64): hrnet_bwd_pw_supported(). `rows` (the next BatchNorm's backward sums,
- * [splits][2][Cin]) only where hrnet_bwd_pw_rows_supported() (Cin <= 64); otherwise pass NULL and run
- * hrnet_bn_bwd_reduce on dx.
+ * [splits][2][Cin]) where hrnet_bwd_pw_rows_supported() (every served shape).
  */
 int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x,
                             const float* in_scale, const float* in_shift, int in_relu, const void* wT, void* dx,

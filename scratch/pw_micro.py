@@ -5,7 +5,7 @@ import hip_helpers as hh
 from hipnet import _capi as C
 d = 'cuda'
 P = 64 * 64 * 64
-for Cin, Cout, aff, add, rows in ((64, 256, True, False, True), (256, 64, False, True, False), (64, 64, True, True, True)):
+for Cin, Cout, aff, add, rows in ((64, 256, True, False, True), (256, 64, False, True, True), (64, 64, True, True, True)):
     dz = torch.randn(P, Cout, device=d).bfloat16(); y = torch.randn(P, Cout, device=d).bfloat16()
     x = torch.randn(P, Cin, device=d).bfloat16(); addend = torch.randn(P, Cin, device=d).bfloat16(); bsy = torch.randn(P, Cin, device=d).bfloat16()
     wT = torch.randn(Cin, Cout, device=d).bfloat16(); coef = torch.randn(3 * Cout, device=d); sc = torch.rand(Cin, device=d); sh = torch.rand(Cin, device=d)

@@ -25,13 +25,14 @@ def _q(t):
 CASES = [
     # N, H, W, Cin, Cout, affine+relu on x, addend, mask_out, coef, rows
     (2, 16, 16, 64, 256, True, False, True, True, True),      # conv3 of a Bottleneck: x = relu(bn2(y2)), rows for bn2
-    (2, 16, 16, 256, 64, False, True, True, True, False),     # conv1: stored block input, residual stream added
+    (2, 16, 16, 256, 64, False, True, True, True, True),      # conv1: stored block input, residual stream added, rows through LDS
     (2, 16, 16, 64, 64, True, True, True, True, True),        # layer1.0.conv1 (64 -> 64) behind the stem
     (1, 9, 7, 64, 256, True, False, True, True, True),        # 63 pixels: one partial tile
-    (3, 11, 13, 256, 64, False, True, True, True, False),     # 429 pixels: ragged last tile
+    (3, 11, 13, 256, 64, False, True, True, True, True),      # 429 pixels: ragged last tile
     (1, 8, 8, 64, 256, False, False, False, False, False),    # bare: g = dz, no mask, no statistics
     (12, 64, 64, 64, 256, True, False, True, True, True),     # 768 tiles: every workgroup walks 3 tiles (256 workgroups)
-    (12, 64, 64, 256, 64, False, True, True, True, False),
+    (12, 64, 64, 256, 64, False, True, True, True, True),
+    (2, 16, 16, 256, 64, False, False, False, True, True),    # wide side, statistics without mask or addend
 ]
 
 
@@ -43,7 +44,7 @@ def test_fused_backward_of_conv1x1_bn(case):
     dt = hh.dt_id(DT)
     assert C.call('hrnet_bwd_pw_supported', dt, Cin, Cout) == 1
     assert C.call('hrnet_bwd_pw_supported', hh.dt_id(torch.float32), Cin, Cout) == 0     # fp32 keeps the unfused kernels
-    assert C.call('hrnet_bwd_pw_rows_supported', dt, Cin, Cout) == (1 if Cin <= 64 else 0)
+    assert C.call('hrnet_bwd_pw_rows_supported', dt, Cin, Cout) == 1
     g = torch.Generator().manual_seed(7 + Cin + Cout + N)
     w = _q(torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin))
     x = _q(torch.randn(N, Cin, H, W, generator=g))
@@ -107,16 +108,6 @@ def test_fused_backward_of_conv1x1_bn(case):
         assert float((r[0] - want_rows[0]).abs().max()) <= 2 * TOL * scale
         scale2 = (v.double() * bsy.double()).abs().sum((0, 2, 3)).max().item()
         assert float((r[1] - want_rows[1]).abs().max()) <= 2 * TOL * scale2
-
-
-def test_rows_request_for_a_wide_input_side_is_refused():
-    hh = _h()
-    from hipnet import _capi as C
-    d = hh.DEV
-    t = torch.zeros(64, 256, dtype=DT, device=d)
-    with pytest.raises(RuntimeError, match='no statistics rows'):
-        C.call('hrnet_conv1x1_bwd_fused', 1, t.data_ptr(), None, None, t.data_ptr(), None, None, 0, t.data_ptr(),
-               t.data_ptr(), None, 0, t.data_ptr(), None, t.data_ptr(), 64, 256, 64, C.stream_ptr())
 
 
 def test_fused_pointwise_backward_in_place_on_the_residual_stream():
