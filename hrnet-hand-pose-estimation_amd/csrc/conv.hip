@@ -75,6 +75,8 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.in_relu = op.i[11]; a.upz = upz; a.accumulate = op.i[12];
   const int mode = conv_mode(a, op.i[11] != 0);
+  HR_REQUIRE(!a.in_sums || mode == CONV_FWD || mode == CONV_FWDB,
+             "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
   // input gradient of a 3x3 stride-2 conv: the input-gradient bodies evaluate the four output parities
   // from the real dY tile (S2D, template stride 4); other modes read it as a zero-stuffed grid
   const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);

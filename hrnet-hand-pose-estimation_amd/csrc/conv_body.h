@@ -120,7 +120,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   constexpr bool NO_STATS = MODE == CONV_DG;
   using C = ConvCfg<T, KS, STRIDE, TH, TW, BN, WP, WC, KM>;
   constexpr int VEC = C::VEC;
-  constexpr bool TAB = MODE == CONV_FWD || MODE == CONV_FWDB || MODE == CONV_GENERIC;   // modes that can read a BatchNorm'd input
+  // modes that can read an input BatchNorm given as batch sums (training forward launches). The generic kernel
+  // (eval-mode forward: precomputed scale/shift) stays without the table: its LDS and code cost 4-7 % there
+  constexpr bool TAB = MODE == CONV_FWD || MODE == CONV_FWDB;
   __shared__ __attribute__((aligned(16))) char lds[C::LDSB + (TAB ? 2 * HR_CONV_MAXC * 4 : 0)];
   char* xl = lds;
   char* wl = lds + C::XBYTES;

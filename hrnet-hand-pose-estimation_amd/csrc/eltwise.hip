@@ -107,11 +107,13 @@ struct SumArgs {
 
 constexpr int SUM_MAXC = 384;
 
-template <typename T>
+// SUMS: some term's BatchNorm comes as batch sums (training forward); the plain instantiation (eval forward,
+// deterministic training) carries neither the table nor the per-term test in its inner loop
+template <typename T, bool SUMS>
 __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
   constexpr int VEC = TT<T>::VEC;
-  __shared__ float tab[4][2][SUM_MAXC];
-  if (a.sums_mode) {
+  __shared__ float tab[SUMS ? 4 : 1][2][SUMS ? SUM_MAXC : 1];
+  if (SUMS && a.sums_mode) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t < a.nterms && ((a.sums_mode >> t) & 1)) {
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
         const size_t off = ((size_t)((n * hs + (oy >> sh)) * ws + (ox >> sh)) * a.C + c) * sizeof(T);
         float f[VEC];
         v16_unpack<T>(*(const V16*)(a.src[t] + off), f);
-        if ((a.sums_mode >> t) & 1) {
+        if (SUMS && ((a.sums_mode >> t) & 1)) {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], tab[t][0][c + j], tab[t][1][c + j]);
+          for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], tab[SUMS ? t : 0][0][SUMS ? c + j : 0], tab[SUMS ? t : 0][1][SUMS ? c + j : 0]);
         } else if (a.scale[t]) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], a.scale[t][c + j], a.shift[t][c + j]);
@@ -896,6 +898,14 @@ __global__ __launch_bounds__(256) void bn_finalize_table_kernel(const HrBnEnt* t
   }
   const HrBnEnt e = tab[lo];
   const int c = ((int)blockIdx.x - e.block0) * 256 + threadIdx.x;
+  if (c < e.C && !e.sums) {
+    // eval mode: the affine of the running statistics (same arithmetic as bn_finalize_kernel, training = 0)
+    const float invstd = 1.0f / sqrtf(e.running_var[c] + e.eps);
+    const float sc = e.gamma[c] * invstd;
+    e.scale[c] = sc;
+    e.shift[c] = e.beta[c] - e.running_mean[c] * sc;
+    return;
+  }
   if (c < e.C) {
     float sc, sh, mean, invstd, var;
     hr_bn_from_sums(e.sums, e.C, c, 1.0f / e.count, e.eps, e.gamma[c], e.beta[c], sc, sh, mean, invstd, var);
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(256) void bn_finalize_table_kernel(const HrBnEnt* t
       e.running_var[c] = (1.f - e.momentum) * e.running_var[c] + e.momentum * unbiased;
     }
   }
-  if (e.num_batches_tracked && (int)blockIdx.x == e.block0 && threadIdx.x == 0) *e.num_batches_tracked += 1;
+  if (e.sums && e.num_batches_tracked && (int)blockIdx.x == e.block0 && threadIdx.x == 0) *e.num_batches_tracked += 1;
 }
 
 __global__ __launch_bounds__(256) void fill_zero_kernel(V16* p, long long n16, char* tail, int ntail) {
@@ -963,9 +973,11 @@ int hr_launch_sum_terms(const HrOp& op, hipStream_t s) {
   }
   const long long total = (long long)a.N * a.Ho * a.Wo * (a.C / (dtype == HR_F32 ? 4 : 8));
   if (dtype == HR_F32)
-    hipLaunchKernelGGL(sum_terms_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+    if (a.sums_mode) hipLaunchKernelGGL((sum_terms_kernel<float, true>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((sum_terms_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(sum_terms_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+    if (a.sums_mode) hipLaunchKernelGGL((sum_terms_kernel<bf16_t, true>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((sum_terms_kernel<bf16_t, false>), dim3(ew_grid(total)), dim3(256), 0, s, a);
   return hr_check_launch("sum_terms");
 }
 

@@ -299,6 +299,13 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   return ns;
 }
 
+// workgroups per split of a weight-gradient launch (output-channel blocks x input-channel chunks): a launch runs
+// splits x this many workgroups
+extern "C" int hrnet_wgrad_blocks_per_split(int dtype, int Ho, int Wo, int Cout, int Cin, int ks, int stride) {
+  const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);
+  return ((Cout + c.bco - 1) / c.bco) * ((Cin + c.kc - 1) / c.kc);
+}
+
 // pixel tiles a weight-gradient launch walks (each of the hrnet_wgrad_splits() splits takes tiles/splits of them)
 extern "C" int hrnet_wgrad_tiles(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride) {
   const WgCfg c = choose_wg(dtype, Ho, Wo, Cout, ks, stride, Cin);

@@ -92,6 +92,7 @@ _SIGS = {
     'hrnet_bwd_pw_kernel_name': [_c_int] * 3 + [ctypes.c_char_p, _c_int],
     'hrnet_wgrad_splits': [_c_int] * 8,
     'hrnet_wgrad_tiles': [_c_int] * 8,
+    'hrnet_wgrad_blocks_per_split': [_c_int] * 7,
     'hrnet_wgrad_reduce': [_c_vp, _c_vp] + [_c_int] * 8 + [_c_vp],
     'hrnet_pack_weights': [_c_int, _c_vp, _c_vp] + [_c_int] * 6 + [_c_vp],
     'hrnet_pack_weights_table': [_c_int, _c_vp, _c_int, _c_int, _c_vp],
@@ -128,7 +129,7 @@ _SIGS = {
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])

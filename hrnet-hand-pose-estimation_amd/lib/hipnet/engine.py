@@ -377,11 +377,11 @@ class Plan(object):
             self.fwd.add(C.OP_FILL, ints=(nbytes & 0xffffffff, nbytes >> 32), ptrs=(C.ptr(self.bn_arena),))
         cv, bn = net.convs, self.bns
         if not self.training:
-            for b in self.bns.values():
-                m = b.mod
-                self.fwd.add(C.OP_BN_FINALIZE, ints=(0, b.C, 0), floats=(1.0, 0.1, m.eps),
-                             ptrs=(None, C.ptr(m.weight), C.ptr(m.bias), C.ptr(m.running_mean),
-                                   C.ptr(m.running_var), None, C.ptr(b.scale), C.ptr(b.shift), None, None))
+            # eval mode: every BatchNorm's affine from its running statistics, ONE table launch (306 launches of
+            # 12 us each before: a third of the isolated kernel time of an eval forward pass)
+            self.bn_finalize_list = list(self.bns.values())
+            self._add_bn_finalize_table(eval_mode=True)
+            self.bn_finalize_list = []
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
         cols = self._act('stem.cols', N, Ho, Wo, 32, grad=False)
         self.in_op = self.fwd.add(C.OP_IM2COL_STEM, ints=(self.dtid, N, 3, H, W, Ho, Wo, 32),
@@ -444,16 +444,17 @@ class Plan(object):
         self.fwd.finalize()
         self.bwd.finalize()
 
-    def _add_bn_finalize_table(self):
+    def _add_bn_finalize_table(self, eval_mode=False):
         ents = (C.HrBnEnt * len(self.bn_finalize_list))()
         block = 0
         for e, b in zip(ents, self.bn_finalize_list):
             m = b.mod
-            e.sums, e.gamma, e.beta = C.ptr(b.sums), C.ptr(m.weight), C.ptr(m.bias)
+            e.sums, e.gamma, e.beta = (None if eval_mode else C.ptr(b.sums)), C.ptr(m.weight), C.ptr(m.bias)
             e.running_mean, e.running_var = C.ptr(m.running_mean), C.ptr(m.running_var)
-            e.num_batches_tracked = C.ptr(m.num_batches_tracked)
+            e.num_batches_tracked = None if eval_mode else C.ptr(m.num_batches_tracked)
             e.scale, e.shift, e.mean, e.invstd = C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.mean), C.ptr(b.invstd)
-            e.count, e.momentum, e.eps = b.count, (m.momentum if m.momentum is not None else 0.1), m.eps
+            e.count = 1.0 if eval_mode else b.count
+            e.momentum, e.eps = (m.momentum if m.momentum is not None else 0.1), m.eps
             e.C, e.block0 = b.C, block
             block += (b.C + 255) // 256
         raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
@@ -618,6 +619,13 @@ class Plan(object):
         self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not dp and not self.wlane
                             and os.environ.get('HRNET_DEFER_WGRAD', '1') != '0')
         self.defer_branch_wgrads = os.environ.get('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
+        # how much weight-gradient work the single-lane tail can hide: the tail is a stream over the stem / layer1
+        # maps, so its length goes with their pixel count; 3.2 MFLOP per tail pixel is what w32 at B=64 hides in full
+        # (773 GFLOP behind a 4 ms tail). w48 has 1.9x the work per tail pixel: half of it stays in the modules
+        # (deferring all of it: 43.8 ms/step, none: 37.0)
+        tail_pixels = self.N * (self.H // 4) * (self.W // 4)
+        self._defer_budget = float(os.environ.get('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
+        self._defer_flops = 0.0
         self._deferred = []
         self._deferred_lanes = []
         self.n_deferred_wgrads = 0
@@ -727,16 +735,23 @@ class Plan(object):
                     self.bwd.sync(lane, self.wlane)
                     self.bwd.lane = self.wlane
                 nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
+                wflops = 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks
                 deferred = (self.batch_wred and self.defer_wgrad and in_region and first_fork is not None
                             and ti > first_fork
-                            and (self.defer_branch_wgrads or '.branches.' not in crec.prefix))
+                            and (self.defer_branch_wgrads or '.branches.' not in crec.prefix)
+                            and self._defer_flops + wflops <= self._defer_budget)
+                if deferred:
+                    self._defer_flops += wflops
                 if deferred and nsplit > 1:
                     # A deferred launch runs in the background of the single-lane tail: it does not need the
-                    # parallelism of many splits, and every split is a slab written and read back.
-                    # measured (ms/step): divisor 1: 19.97, 2: 19.56, 4: 19.49, 8: 19.97
+                    # parallelism of many splits, and every split is a slab written and read back - but it must
+                    # keep ~100 workgroups (the wide w48 layers have few splits to begin with: dividing those
+                    # cost 6 ms per step). measured (w32 B=64, ms/step): divisor 1: 19.97, 2: 19.56, 4: 19.49, 8: 19.97
                     div = int(os.environ.get('HRNET_DEFER_SPLIT_DIV', '4'))
                     tiles = C.call('hrnet_wgrad_tiles', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
-                    nsplit = max(1, nsplit // max(div, 1))
+                    per = C.call('hrnet_wgrad_blocks_per_split', self.dtid, y.H, y.W, y.C, x.C, ks, stride)
+                    floor_ = min(nsplit, -(-96 // max(per, 1)))
+                    nsplit = max(1, floor_, nsplit // max(div, 1))
                     while nsplit > 1 and tiles % nsplit != 0:
                         nsplit -= 1
                 wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit)

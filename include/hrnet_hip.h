@@ -154,6 +154,8 @@ int hrnet_conv2d_wgrad(int dtype, const void* x, const void* dy, const float* in
 int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
 /* pixel tiles the launch walks in all (a split takes tiles / nsplit of them, grid-strided) */
 int hrnet_wgrad_tiles(int dtype, int N, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
+/* workgroups per split (a launch runs splits x this many) */
+int hrnet_wgrad_blocks_per_split(int dtype, int Ho, int Wo, int Cout, int Cin, int ks, int stride);
 /* slabs -> grad_oihw[Cout_real][Cin_real][ks][ks] f32 (+= if accumulate). Cout/Cin are the
  * padded slab extents; stem: kflat=1 means slab K index is the flattened (tap,ci) of the
  * im2col'ed stem (Cin_real*ks*ks real entries). */
@@ -288,7 +290,7 @@ int hrnet_conv2d_bnref(int dtype, const void* x, const void* w, const float* in_
                        float* out_sums, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride,
                        int in_relu, hr_stream_t stream);
 typedef struct HrBnEnt {
-  const float* sums;   /* [8][2][C] */
+  const float* sums;   /* [8][2][C]; NULL: eval mode - scale/shift from running_mean/var, nothing else written */
   const float* gamma;
   const float* beta;
   float* running_mean; /* may be NULL */

@@ -1,0 +1,3 @@
+#!/bin/bash
+run() { echo "== $1"; env $1 python bench.py --arch w48 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; }
+for cfg in "$@"; do run "$cfg"; done
