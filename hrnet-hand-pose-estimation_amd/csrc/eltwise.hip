@@ -670,7 +670,18 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, T* ou
 // 114 MB of weights, 130 us per launch, twice per step). Here a block stages a contiguous piece of the master
 // through LDS: mode 0 one output-channel row (Cin*taps floats, contiguous), mode 1 four input channels of every
 // output channel (4*taps contiguous floats per row), and writes its packed rows with unit stride.
-constexpr int PACK_LDS_FLOATS = 19456;      // 76 KB: mode 1 needs Cout * (4*taps + 1) floats (Cout <= 512 at 3x3)
+// 19 KB of staging (eight workgroups per CU): mode 1 takes 16 ... 1 input channels per block, whichever fits
+constexpr int PACK_LDS_FLOATS = 4864;
+__host__ __device__ inline int pack_nci(int Cout, int taps) {
+  for (int p = 16; p > 1; p >>= 1)
+    if (Cout * (p * taps + 1) <= PACK_LDS_FLOATS) return p;
+  return 1;
+}
+// mode 0: output-channel rows per block (narrow layers: a 32-channel 3x3 row is 1.1 KB - several per block)
+__host__ __device__ inline int pack_rows(int Cin_pad, int taps) {
+  const int r = 2048 / (Cin_pad * taps);
+  return r < 1 ? 1 : (r > 8 ? 8 : r);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, int n) {
@@ -687,19 +698,24 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, i
   const int u = (int)blockIdx.x - e.block0;
   if (e.mode == 0) {
     // out[co][t][ci_pad] <- w[co][ci][t]
-    const int co = u, rowlen = e.Cin * taps;
-    if (co < e.Cout)
-      for (int i = threadIdx.x; i < rowlen; i += 256) buf[i] = w[(size_t)co * rowlen + i];
+    const int nr = pack_rows(e.Cin_pad, taps), co0 = u * nr, rowlen = e.Cin * taps, olen = taps * e.Cin_pad;
+    const int rows = e.Cout_pad - co0 < nr ? e.Cout_pad - co0 : nr;
+    for (int i = threadIdx.x; i < rows * rowlen; i += 256) {      // consecutive master rows are contiguous
+      const int r = i / rowlen;
+      buf[i] = co0 + r < e.Cout ? w[(size_t)co0 * rowlen + i] : 0.f;
+    }
     __syncthreads();
-    T* o = out + (size_t)co * taps * e.Cin_pad;
-    for (int idx = threadIdx.x; idx < taps * e.Cin_pad; idx += 256) {
-      const int t = idx / e.Cin_pad, ci = idx - t * e.Cin_pad;
-      o[idx] = (T)((co < e.Cout && ci < e.Cin) ? buf[ci * taps + t] : 0.f);
+    T* o = out + (size_t)co0 * olen;
+    for (int idx = threadIdx.x; idx < rows * olen; idx += 256) {
+      const int r = idx / olen, q = idx - r * olen;
+      const int t = q / e.Cin_pad, ci = q - t * e.Cin_pad;
+      o[idx] = (T)((co0 + r < e.Cout && ci < e.Cin) ? buf[r * rowlen + ci * taps + t] : 0.f);
     }
   } else if (e.mode == 1) {
     // out[ci][taps flipped][co_pad] <- w[co][ci][t]
-    const int ci0 = u * 4, span = 4 * taps, pitch = span + 1;
-    const int nci = e.Cin_pad - ci0 < 4 ? e.Cin_pad - ci0 : 4;
+    const int per = pack_nci(e.Cout_pad, taps);     // (same rule as hrnet_pack_blocks)
+    const int ci0 = u * per, span = per * taps, pitch = span + 1;
+    const int nci = e.Cin_pad - ci0 < per ? e.Cin_pad - ci0 : per;
     for (int i = threadIdx.x; i < e.Cout * span; i += 256) {
       const int co = i / span, r = i - co * span;
       const int ci = ci0 + r / taps;
@@ -1024,9 +1040,14 @@ int hr_launch_grad_term(const HrOp& op, hipStream_t s) {
 }
 
 extern "C" int hrnet_pack_blocks(int Cout_pad, int Cin_pad, int ks, int mode) {
-  if (mode == 0) return Cout_pad;
-  if (mode == 1) return (Cin_pad + 3) / 4;
-  (void)ks;
+  if (mode == 0) {
+    const int nr = pack_rows(Cin_pad, ks * ks);
+    return (Cout_pad + nr - 1) / nr;
+  }
+  if (mode == 1) {
+    const int per = pack_nci(Cout_pad, ks * ks);
+    return (Cin_pad + per - 1) / per;
+  }
   return (int)(((long long)Cout_pad * Cin_pad + 1023) / 1024);
 }
 

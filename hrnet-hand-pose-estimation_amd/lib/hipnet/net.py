@@ -82,7 +82,7 @@ class HipNet(object):
         block = 0
         for e, (r, mode, out) in zip(ents, items):
             taps = r.ks * r.ks
-            if mode == 1 and r.Cout * (4 * taps + 1) > 19456:
+            if (mode == 1 and r.Cout_pad * (taps + 1) > 4864) or (mode == 0 and r.Cin * taps > 4864):
                 raise ValueError('{}: {} output channels at {}x{} exceed the LDS staging of the weight packer'.format(
                     r.prefix, r.Cout, r.ks, r.ks))
             e.w, e.out = C.ptr(r.mod.weight), C.ptr(out)

@@ -239,7 +239,9 @@ int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, int Cout, i
                        int Cout_pad, int Cin_pad, int mode, hr_stream_t stream);
 /* The same for every convolution of a network in ONE launch: `table` is a DEVICE array of n
  * entries; entry e covers blocks [block0, block0 + hrnet_pack_blocks(Cout_pad, Cin_pad, ks, mode));
- * total_blocks = their sum. Mode 1 stages Cout * (4*ks*ks + 1) floats per block in LDS: at most 19456. */
+ * total_blocks = their sum. A block stages a master row (mode 0: Cin*ks*ks floats) or 4/2/1 input channels of
+ * every output channel (mode 1: Cout_pad * (n*ks*ks + 1) floats) in 19 KB of LDS: Cin*ks*ks and
+ * Cout_pad*(ks*ks+1) must not exceed 4864. */
 typedef struct HrPackEnt {
   const void* w;   /* f32 OIHW master weights */
   void* out;       /* packed weights */
