@@ -54,9 +54,27 @@ def build_model(dtype, yaml_name):
 
 
 def conv_flops_table(plan):
-    """algorithmic FLOPs of every MFMA op of the recorded programs + its kernel instantiation name"""
+    """algorithmic FLOPs and algorithmic HBM bytes of every MFMA op of the recorded programs + its kernel
+    instantiation name. Bytes = every operand tensor once (no halo re-reads, no split-K slabs):
+      conv / input gradient: input + output tensor (+ the two tensors of the fused backward-statistics epilogue);
+      weight gradient: the two operand tensors; fused backward (3x3 and 1x1): dz, y, x in, dx out, + the residual
+      addend and the next BatchNorm's raw input when the launch uses them."""
     from hipnet import _capi as C
     buf = ctypes.create_string_buffer(160)
+    es = 4 if plan.dtid == 0 else 2
+
+    def cbytes(op):
+        i = op.i
+        b = (i[1] * i[2] * i[3] * i[4] + i[1] * i[5] * i[6] * i[7]) * es
+        if op.p[7]:
+            b += i[1] * i[5] * i[6] * i[7] * es * (2 if op.p[8] else 1)     # bs_y (+ mask source)
+        return float(b)
+
+    def fbytes(op):
+        i = op.i
+        pix = i[1] * i[2] * i[3]
+        cin_side = 2 + (1 if op.p[8] else 0) + (1 if op.p[10] else 0)      # x, dx (+ addend, + bs_y)
+        return float(pix * es * (2 * i[5] + cin_side * i[4]))
 
     def flops(op, wgrad):
         i = op.i
@@ -76,17 +94,18 @@ def conv_flops_table(plan):
                               1 if op.p[6] else 0, 1 if op.p[2] else 0, op.i[11])
                 C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[4], op.i[7], op.i[8],
                        op.i[9], op.i[10], mode, buf, 160)
-                out[(pname, idx)] = (buf.value.decode(), flops(op, False))
+                out[(pname, idx)] = (buf.value.decode(), flops(op, False), cbytes(op))
             elif op.kind == C.OP_BWD_FUSED:
                 # weight gradient + input gradient of one 3x3 conv in one launch: 2 x the forward conv's FLOPs
                 C.call('hrnet_bwd_fused_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
-                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5] * 9)
+                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5] * 9, fbytes(op))
             elif op.kind == C.OP_BWD_PW:
                 C.call('hrnet_bwd_pw_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
-                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5])
+                out[(pname, idx)] = (buf.value.decode(), 2 * 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5], fbytes(op))
             elif op.kind == C.OP_WGRAD:
                 C.call('hrnet_wgrad_kernel_name', op.i[0], op.i[5], op.i[6], op.i[7], op.i[4], op.i[8], op.i[9], buf, 160)
-                out[(pname, idx)] = (buf.value.decode(), flops(op, True))
+                out[(pname, idx)] = (buf.value.decode(), flops(op, True),
+                                     float((op.i[1] * op.i[2] * op.i[3] * op.i[4] + op.i[1] * op.i[5] * op.i[6] * op.i[7]) * es))
     return out
 
 
@@ -164,9 +183,9 @@ def instrumented_step(model, x, gt, criterion):
             ms = e0.elapsed_time(e1)
             key = (pname, idx)
             if key in table:
-                name, fl = table[key]
-                s = stats.setdefault(name, [0, 0.0, 0.0])
-                s[0] += 1; s[1] += ms; s[2] += fl
+                name, fl, by = table[key]
+                s = stats.setdefault(name, [0, 0.0, 0.0, 0.0])
+                s[0] += 1; s[1] += ms; s[2] += fl; s[3] += by
             k = kinds.setdefault(int(prog.ops[idx].kind), [0, 0.0])
             k[0] += 1; k[1] += ms
     net.mark_weights_dirty()
@@ -428,17 +447,29 @@ def main():
         stats, kinds = instrumented_step(model, x, gt, criterion)
         peak = PEAK_TFLOPS[args.dtype]
         dom = max(stats.items(), key=lambda kv: kv[1][1])
-        name, (n, ms, fl) = dom
+        name, (n, ms, fl, by) = dom
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 5), 'traffic': traffic_of(name), 'kernel': name, 'launches_per_step': n,
-                'avg_launch_us': round(ms / n * 1e3, 2)}
+        ach_bw = by / (ms * 1e-3) / 1e9                      # GB/s of algorithmic bytes
+        # the roof that binds this kernel: the larger of (FLOP / MFMA peak) and (algorithmic bytes / HBM peak)
+        if by / 8000e9 > fl / (peak * 1e12):
+            roof = {'bound': 'hbm', 'achieved': round(ach_bw, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(ach_bw / 8000.0, 5)}
+        else:
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 5)}
+        roof.update({'traffic': traffic_of(name), 'kernel': name, 'launches_per_step': n,
+                     'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_mb_per_launch': round(by / n / 1e6, 2),
+                     'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3), 'mfma_frac': round(ach / peak, 5),
+                     'hbm_frac': round(ach_bw / 8000.0, 5)})
         mfma_ms = sum(v[1] for v in stats.values())
         mfma_fl = sum(v[2] for v in stats.values())
+        mfma_by = sum(v[3] for v in stats.values())
         extra_out['mfma_kernels'] = {
             'ms_per_step': round(mfma_ms, 3), 'tflops': round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2),
             'frac_of_peak': round(mfma_fl / (mfma_ms * 1e-3) / 1e12 / peak, 5),
-            'algorithmic_gflop_per_img': round(mfma_fl / args.batch / 1e9, 2)}
+            'algorithmic_gflop_per_img': round(mfma_fl / args.batch / 1e9, 2),
+            'algorithmic_gb_per_step': round(mfma_by / 1e9, 2),
+            'hbm_frac_of_peak': round(mfma_by / (mfma_ms * 1e-3) / 8000e9, 5)}
         extra_out['kernel_ms'] = {k: [v[0], round(v[1], 3)] for k, v in
                                   sorted(stats.items(), key=lambda kv: -kv[1][1])}
         plan_ = model.hip().plan(x.shape[0], x.shape[2], x.shape[3], True, True)
