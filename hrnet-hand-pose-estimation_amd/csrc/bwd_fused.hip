@@ -578,12 +578,15 @@ inline FusedCfg fused_cfg(int dtype, int Cout) {
     if (var == 2) return FusedCfg{64, 8, 4, 2, 2, 0, 2};
     return FusedCfg{64, 16, 8, 2, 4, 0, 1};
   }
+  // 128 output-side channels (the third branch: 16x16 maps): 8x16 tiles so that the g image (49 KB), the 32-channel
+  // input image (14 KB) and the 32 x 9 x 128 weights (74 KB) share one CU's LDS
+  if (Cout <= 128) return FusedCfg{128, 8, 8, 2, 4, 0, 1};
   return FusedCfg{0, 0, 0, 0, 0, 0, 0};
 }
 
 }  // namespace
 
-// 1 if hrnet_conv3x3_bwd_fused serves this layer (3x3 stride 1, Cout <= 64 for bf16 / <= 32 for f32)
+// 1 if hrnet_conv3x3_bwd_fused serves this layer (3x3 stride 1, Cout <= 128 for bf16 / <= 32 for f32)
 extern "C" int hrnet_bwd_fused_supported(int dtype, int Cin, int Cout) {
   if (dtype != HR_F32 && dtype != HR_BF16) return 0;
   if (Cin % (dtype == HR_F32 ? 4 : 8) != 0 || Cout % 16 != 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -668,6 +671,7 @@ extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const vo
   else if (c.cop == 32 && c.nw == 8) FUSED(bf16_t, 32, 16, 8, 1, 8, false);
   else if (c.cop == 32 && c.th == 16) FUSED(bf16_t, 32, 16, 4, 1, 4, false);
   else if (c.cop == 32) FUSED(bf16_t, 32, 8, 4, 1, 4, false);
+  else if (c.cop == 128) FUSED(bf16_t, 128, 8, 8, 2, 4, false);
   else if (c.nw == 8) FUSED(bf16_t, 64, 16, 8, 2, 4, false);
   else FUSED(bf16_t, 64, 8, 4, 2, 2, false);
 #undef FUSED

@@ -833,6 +833,8 @@ class Plan(object):
         if not self.training or os.environ.get('HRNET_FUSED_BWD', '1') == '0':
             return out
         T, L = self.tape, self.tape_lanes
+        # (the 128-channel instantiation exists and is tested, but inside the step it loses: 19.32 vs 18.82 ms - its four
+        # input-channel blocks re-stage the same 128-channel g tile and a third 128-CU grid queues behind the other two)
         maxc = int(os.environ.get('HRNET_FUSED_MAXC', '64'))     # (tests: restrict the fused path to narrow layers)
         for ti in range(2, len(T)):
             e = T[ti]
