@@ -95,6 +95,11 @@ def conv_flops_table(plan):
                 C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[5], op.i[6], op.i[4], op.i[7], op.i[8],
                        op.i[9], op.i[10], mode, buf, 160)
                 out[(pname, idx)] = (buf.value.decode(), flops(op, False), cbytes(op))
+            elif op.kind == C.OP_CONV_SUM:
+                # conv whose input is the residual sum formed in its prologue: x, x2 in; side, y out
+                C.call('hrnet_conv_kernel_name', op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], 1, 0, 5, buf, 160)
+                out[(pname, idx)] = (buf.value.decode(), 2.0 * op.i[1] * op.i[2] * op.i[3] * op.i[4] * op.i[5] * op.i[6] * op.i[6],
+                                     float(op.i[1] * op.i[2] * op.i[3] * (3 * op.i[4] + op.i[5]) * es))
             elif op.kind == C.OP_BWD_FUSED:
                 # weight gradient + input gradient of one 3x3 conv in one launch: 2 x the forward conv's FLOPs
                 C.call('hrnet_bwd_fused_kernel_name', op.i[0], op.i[4], op.i[5], buf, 160)
@@ -119,7 +124,7 @@ def traffic_of(kernel_name):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    m = re.match(r'(conv_bs|conv_fwdb|conv_fwd|conv_dg|conv|wgrad|bwd_fused)_kernel<[^,]+, (.*)>', kernel_name)
+    m = re.match(r'(conv_bs|conv_fwdb|conv_fwds|conv_fwd|conv_dg|conv|wgrad|bwd_fused)_kernel<[^,]+, (.*)>', kernel_name)
     if not m:
         m = re.match(r'(bwd_pw)_kernel<()(.*)>', kernel_name)
         if not m:
@@ -474,7 +479,8 @@ def main():
                                   sorted(stats.items(), key=lambda kv: -kv[1][1])}
         plan_ = model.hip().plan(x.shape[0], x.shape[2], x.shape[3], True, True)
         extra_out['launches_per_step'] = {'fwd': len(plan_.fwd), 'bwd': len(plan_.bwd),
-                                          'fused_blocks': plan_.n_fused_blocks, 'deferred_wgrads': plan_.n_deferred_wgrads}
+                                          'fused_blocks': plan_.n_fused_blocks, 'deferred_wgrads': plan_.n_deferred_wgrads,
+                                          'fused_sums': plan_.n_fused_sums}
         extra_out['wgrad_slab_mb_per_step'] = round(plan_.slab_bytes / 1e6, 1)
         extra_out['critical_path_ms'] = kinds.pop('critical_path_ms')
         extra_out['op_kind_ms'] = {str(k): [v[0], round(v[1], 3)] for k, v in sorted(kinds.items())}

@@ -208,4 +208,5 @@ int hr_launch_pack_table(const HrOp& op, hipStream_t s);
 int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s);
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s);
 int hr_launch_bwd_pw(const HrOp& op, hipStream_t s);
+int hr_launch_conv_sum(const HrOp& op, hipStream_t s);
 int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s);

@@ -112,6 +112,66 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   }
 }
 
+// HR_OP_CONV_SUM: i = dtype,N,H,W,Cin,Cout,ks,stats_atomic; f = 1/count, eps;
+// p = x, w, in_scale, in_shift, in_sums, in_gamma, in_beta, y, stats, x2, side
+int hr_launch_conv_sum(const HrOp& op, hipStream_t s) {
+  const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cin = op.i[4], Cout = op.i[5], ks = op.i[6];
+  HR_REQUIRE(dtype == HR_F32 || dtype == HR_BF16, "conv2d_sum: bad dtype %d", dtype);
+  HR_REQUIRE(ks == 1 || ks == 3, "conv2d_sum: kernel size %d", ks);
+  HR_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_sum: empty shape");
+  HR_REQUIRE(Cin % (dtype == HR_F32 ? 4 : 8) == 0 && Cout % 16 == 0, "conv2d_sum: channel counts (Cin=%d Cout=%d)", Cin, Cout);
+  HR_REQUIRE((double)H * W * (Cin > Cout ? Cin : Cout) * 4.0 < 2147483648.0, "conv2d_sum: one image exceeds 2 GiB");
+  ConvArgs a = {};
+  a.x = (const char*)op.p[0];
+  a.w = (const char*)op.p[1];
+  a.in_scale = (const float*)op.p[2];
+  a.in_shift = (const float*)op.p[3];
+  a.in_sums = (const float*)op.p[4];
+  a.in_gamma = (const float*)op.p[5];
+  a.in_beta = (const float*)op.p[6];
+  a.y = (char*)op.p[7];
+  a.stats = (float*)op.p[8];
+  a.x2 = (const char*)op.p[9];
+  a.side = (char*)op.p[10];
+  a.in_inv_count = op.f[0];
+  a.in_eps = op.f[1];
+  a.stats_atomic = op.i[7];
+  HR_REQUIRE(a.x && a.w && a.y && a.x2 && a.side, "conv2d_sum: null pointer");
+  HR_REQUIRE((a.in_scale != nullptr) == (a.in_shift != nullptr), "conv2d_sum: scale/shift must come together");
+  HR_REQUIRE((a.in_scale != nullptr) != (a.in_sums != nullptr), "conv2d_sum: the BatchNorm term needs scale/shift OR batch sums");
+  HR_REQUIRE(!a.in_sums || (a.in_gamma && a.in_beta && Cin <= HR_CONV_MAXC && a.in_inv_count > 0.f),
+             "conv2d_sum: batch sums need gamma/beta, Cin <= %d", HR_CONV_MAXC);
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
+  a.in_relu = 1; a.upz = 0; a.accumulate = 0;
+  a.Hz = H; a.Wz = W;
+  const TileChoice tc = choose_tile(N, H, W, Cout, ks, 1, false, false);
+  a.tiles_y = (H + tc.th - 1) / tc.th;
+  a.tiles_x = (W + tc.tw - 1) / tc.tw;
+  a.total_tiles = N * a.tiles_y * a.tiles_x;
+  a.tpw = tc.tpw;
+  a.gx = tc.gx;
+  a.gy = (Cout + tc.bn - 1) / tc.bn;
+  ConvLaunch l;
+  l.a = a; l.tc = tc; l.dtype = dtype; l.N = N; l.ks = ks; l.stride = 1;
+  return hr_conv_launch_fwds(l, s);
+}
+
+extern "C" int hrnet_conv2d_sum(int dtype, const void* x, const void* x2, const void* w, const float* in_scale,
+                                const float* in_shift, const float* in_sums, const float* in_gamma,
+                                const float* in_beta, float in_inv_count, float in_eps, void* side, void* y,
+                                float* stats, int stats_atomic, int N, int H, int W, int Cin, int Cout, int ks,
+                                hr_stream_t stream) {
+  HrOp op = {};
+  op.kind = HR_OP_CONV_SUM;
+  const int iv[8] = {dtype, N, H, W, Cin, Cout, ks, stats_atomic};
+  for (int k = 0; k < 8; ++k) op.i[k] = iv[k];
+  op.f[0] = in_inv_count; op.f[1] = in_eps;
+  op.p[0] = (void*)x; op.p[1] = (void*)w; op.p[2] = (void*)in_scale; op.p[3] = (void*)in_shift;
+  op.p[4] = (void*)in_sums; op.p[5] = (void*)in_gamma; op.p[6] = (void*)in_beta; op.p[7] = y; op.p[8] = stats;
+  op.p[9] = (void*)x2; op.p[10] = side;
+  return hr_launch_conv_sum(op, (hipStream_t)stream);
+}
+
 extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                             const float* in_shift, const float* bias, void* y, float* stats, int N,
                             int H, int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride,
@@ -175,7 +235,8 @@ extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin,
   static const int wp[8] = {4, 2, 2, 2, 2, 0, 4, 2}, wc[8] = {1, 2, 2, 2, 2, 0, 1, 2};
   const int kstride = s2d ? 4 : (ks == 1 || upz) ? 1 : stride;
   const int km = conv_km(dtype, ks, Cin, tc.id);
-  static const char* names[5] = {"conv_kernel", "conv_bs_kernel", "conv_fwd_kernel", "conv_dg_kernel", "conv_fwdb_kernel"};
-  return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", names[mode >= 0 && mode < 5 ? mode : 0],
+  static const char* names[6] = {"conv_kernel", "conv_bs_kernel", "conv_fwd_kernel", "conv_dg_kernel", "conv_fwdb_kernel",
+                                 "conv_fwds_kernel"};
+  return snprintf(buf, buflen, "%s<%s, %d, %d, %d, %d, %d, %d, %d, %d>", names[mode >= 0 && mode < 6 ? mode : 0],
                   dtype == HR_F32 ? "float" : "__bf16", ks, kstride, tc.th, tc.tw, tc.bn, wp[tc.id], wc[tc.id], km);
 }

@@ -57,6 +57,11 @@ struct ConvArgs {
   const float* in_beta;
   float in_inv_count, in_eps;
   int stats_atomic;
+  // CONV_FWDS: the input is the output of a residual sum that is formed HERE, a = relu(scale*x + shift + x2) (the
+  // BasicBlock / Bottleneck tail relu(bn(y) + identity), pose_hrnet.py:54-55, :95-96), and the centre pixels of
+  // every staged tile are also written to `side`: the sum tensor the next residual add and the backward pass read.
+  const char* x2;
+  char* side;
 };
 
 constexpr int HR_CONV_MAXC = 768;   // channels of the on-the-fly coefficient table (w48 head: 720)
@@ -111,7 +116,8 @@ struct ConvCfg {
 //                 zero-stuffing / accumulate
 //   CONV_DG       plain input gradient: raw dY in, no bias, no statistics; zero-stuffing / accumulate by flag
 //   CONV_FWDB     CONV_FWD with a bias (the head convs)
-enum { CONV_GENERIC = 0, CONV_BS = 1, CONV_FWD = 2, CONV_DG = 3, CONV_FWDB = 4 };
+//   CONV_FWDS     CONV_FWD whose input is a residual sum formed in the prologue (two input tensors) and written out
+enum { CONV_GENERIC = 0, CONV_BS = 1, CONV_FWD = 2, CONV_DG = 3, CONV_FWDB = 4, CONV_FWDS = 5 };
 
 template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM, int MODE>
 __device__ __forceinline__ void conv_body(const ConvArgs& a) {
@@ -122,7 +128,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   constexpr int VEC = C::VEC;
   // modes that can read an input BatchNorm given as batch sums (training forward launches). The generic kernel
   // (eval-mode forward: precomputed scale/shift) stays without the table: its LDS and code cost 4-7 % there
-  constexpr bool TAB = MODE == CONV_FWD || MODE == CONV_FWDB;
+  constexpr bool TAB = MODE == CONV_FWD || MODE == CONV_FWDB || MODE == CONV_FWDS;
+  constexpr bool X2 = MODE == CONV_FWDS;
   __shared__ __attribute__((aligned(16))) char lds[C::LDSB + (TAB ? 2 * HR_CONV_MAXC * 4 : 0)];
   char* xl = lds;
   char* wl = lds + C::XBYTES;
@@ -173,7 +180,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     }
   }
   const bool in_relu = RAW_IN ? false : a.in_relu != 0;
-  constexpr bool FWDLIKE = MODE == CONV_FWD || MODE == CONV_FWDB;
+  constexpr bool FWDLIKE = MODE == CONV_FWD || MODE == CONV_FWDB || MODE == CONV_FWDS;
   const bool A_UPZ = FWDLIKE ? false : a.upz != 0;
   const bool A_ACC = FWDLIKE ? false : a.accumulate != 0;
   const bool A_BIAS = MODE == CONV_GENERIC ? a.bias != nullptr : MODE == CONV_FWDB;
@@ -216,6 +223,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 
   // staging registers of the stage in flight
   V16 xr[C::XV], wr[C::WV];
+  V16 x2r[X2 ? C::XV : 1];        // the identity term of the residual sum (CONV_FWDS)
+  char* side_base = nullptr;      // where the staged tile's first halo pixel lives in `side`
   unsigned xok = 0;
   float sc[VEC], sh[VEC];
 
@@ -233,6 +242,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int hy = pix / C::HALO_W, hx = pix % C::HALO_W;
     hyx[k] = (hy << 16) | hx;
     goff[k] = A_UPZ ? 0 : hy * rowB + hx * pixB + v * 16;
+  }
+  // CONV_FWDS: which of this thread's staged vectors are centre (non-halo) pixels of the tile - those are written
+  // to `side`, by the workgroups of the first output-channel block only (every pixel exactly once)
+  unsigned cmask = 0;
+  if constexpr (X2) {
+    constexpr int PADC = KS / 2;
+#pragma unroll
+    for (int k = 0; k < C::XV; ++k) {
+      const int hy = hyx[k] >> 16, hx = hyx[k] & 0xffff;
+      if (hy >= PADC && hy < PADC + TH && hx >= PADC && hx < PADC + TW) cmask |= 1u << k;
+    }
+    if (n0 != 0 || a.side == nullptr) cmask = 0;
   }
   const int ldsx = (tid / C::VPP) * C::PIXB + v * 16;   // + k * (256 / VPP) * PIXB
 
@@ -293,7 +314,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
           xr[k] = *(const V16*)(base + goff[k]);
           xok |= 1u << k;
         }
+        if constexpr (X2) {
+          x2r[k] = v16_zero();
+          if (ok) x2r[k] = *(const V16*)(a.x2 + (base - a.x) + goff[k]);
+        }
       }
+      if constexpr (X2) side_base = a.side + (base - a.x);
     } else {
 #pragma unroll
       for (int k = 0; k < C::XV; ++k) {
@@ -346,6 +372,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   };
 
   auto store_stage = [&](int s) {
+    if constexpr (X2) {
+      // a = relu(scale*x + shift + x2), rounded once: what goes to LDS IS what goes to `side`
+#pragma unroll
+      for (int k = 0; k < C::XV; ++k) {
+        if ((xok >> k) & 1u) {
+          float f[VEC], g2[VEC];
+          v16_unpack<T>(xr[k], f);
+          v16_unpack<T>(x2r[k], g2);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            f[j] = fmaf(f[j], sc[j], sh[j]) + g2[j];
+            f[j] = f[j] > 0.f ? f[j] : 0.f;
+          }
+          xr[k] = v16_pack<T>(f);
+          if ((cmask >> k) & 1u) *(V16*)(side_base + goff[k]) = xr[k];
+        }
+      }
+    } else
     if (has_affine) {
       if (in_relu) xform(std::true_type{}, std::true_type{});
       else xform(std::true_type{}, std::false_type{});
@@ -628,6 +672,11 @@ __global__ __launch_bounds__(256) void conv_fwdb_kernel(ConvArgs a) {
 }
 
 template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
+__global__ __launch_bounds__(256) void conv_fwds_kernel(ConvArgs a) {
+  conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, CONV_FWDS>(a);
+}
+
+template <typename T, int KS, int STRIDE, int TH, int TW, int BN, int WP, int WC, int KM>
 __global__ __launch_bounds__(256) void conv_dg_kernel(ConvArgs a) {
   conv_body<T, KS, STRIDE, TH, TW, BN, WP, WC, KM, CONV_DG>(a);
 }
@@ -686,6 +735,7 @@ inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
     else if constexpr (MODE == CONV_FWD) hipLaunchKernelGGL((conv_fwd_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a); \
     else if constexpr (MODE == CONV_DG) hipLaunchKernelGGL((conv_dg_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);   \
     else if constexpr (MODE == CONV_FWDB) hipLaunchKernelGGL((conv_fwdb_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a); \
+    else if constexpr (MODE == CONV_FWDS) hipLaunchKernelGGL((conv_fwds_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a); \
     else hipLaunchKernelGGL((conv_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, a);                    \
   } while (0)
 
@@ -758,6 +808,7 @@ int hr_conv_launch_generic(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_bs(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_fwd(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_dg(const ConvLaunch& l, hipStream_t s);
+int hr_conv_launch_fwds(const ConvLaunch& l, hipStream_t s);
 int hr_conv_launch_fwdb(const ConvLaunch& l, hipStream_t s);
 
 #define HR_DEFINE_CONV_LAUNCH(NAME, MODE)                                              \

@@ -24,6 +24,7 @@ class HrOp(ctypes.Structure):
 
 OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED, OP_BN_FINALIZE_TABLE = 17, 18, 19, 20, 21, 22
 OP_BWD_PW = 23
+OP_CONV_SUM = 24
 LANE_SLOT = 18
 
 
@@ -70,6 +71,7 @@ _SIGS = {
     'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
     'hrnet_conv2d_bnref': [_c_int] + [_c_vp] * 5 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 10 + [_c_vp],
     'hrnet_bn_finalize_table': [_c_vp, _c_int, _c_int, _c_vp],
+    'hrnet_conv2d_sum': [_c_int] + [_c_vp] * 8 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     'hrnet_sum_terms_bnref': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_int, ctypes.POINTER(ctypes.c_float), _c_float, _c_vp],
     'hrnet_conv_mode': [_c_int] * 7,
     'hrnet_conv_tiles': [_c_int] * 6,

@@ -109,8 +109,11 @@ class Program(object):
         self.events = []
         self._arr = None
         self.tags = {}          # op index -> layer name (measurement scripts only)
+        self.before_add = None  # called before every op is appended (the plan flushes a held-back sum there)
 
     def add(self, kind, ints=(), floats=(), ptrs=(), lane=None):
+        if self.before_add is not None:
+            self.before_add()
         op = C.HrOp()
         op.kind = kind
         for k, v in enumerate(ints):
@@ -276,22 +279,44 @@ class Plan(object):
         bias = crec.mod.bias
         sums_in = self.bn_sums and xin.bn is not None       # the input's BatchNorm from its batch sums, on the fly
         m_in = xin.bn.mod if xin.bn is not None else None
-        i = self.fwd.add(C.OP_CONV,
-                         ints=(self.dtid, x.N, x.H, x.W, cin, Ho, Wo, crec.Cout_pad, ks, stride, 0,
-                               1 if xin.relu else 0, 0, 1 if (want_stats and self.bn_sums) else 0),
-                         floats=((1.0 / xin.bn.count, m_in.eps) if sums_in else ()),
-                         ptrs=(C.ptr(x.t), C.ptr(crec.wf),
-                               C.ptr(xin.bn.scale) if (xin.bn and not sums_in) else None,
-                               C.ptr(xin.bn.shift) if (xin.bn and not sums_in) else None,
-                               C.ptr(self.net.bias_pad[crec.prefix]) if bias is not None else None,
-                               C.ptr(y.t), C.ptr(bnrec.sums) if (want_stats and self.bn_sums) else None,
-                               None, None, None, None,
-                               C.ptr(xin.bn.sums) if sums_in else None, C.ptr(m_in.weight) if sums_in else None,
-                               C.ptr(m_in.bias) if sums_in else None))
+        ps = self._pending_sum
+        if (ps is not None and ps['out'] is x and xin.bn is None and not xin.relu and stride == 1 and not crec.stem
+                and bias is None and ps['lane'] == self.fwd.lane):
+            # the residual sum that produced x has not been emitted: this conv forms it in its prologue and writes
+            # it out on the side (hrnet_conv2d_sum) - one launch and one tensor read less per block
+            self._pending_sum = None
+            bt, it = ps['bn_term'], ps['id_term']
+            sm = self.bn_sums
+            mb = bt.bn.mod
+            i = self.fwd.add(C.OP_CONV_SUM,
+                             ints=(self.dtid, x.N, x.H, x.W, cin, crec.Cout_pad, ks, 1 if (want_stats and sm) else 0),
+                             floats=((1.0 / bt.bn.count, mb.eps) if sm else ()),
+                             ptrs=(C.ptr(bt.act.t), C.ptr(crec.wf),
+                                   None if sm else C.ptr(bt.bn.scale), None if sm else C.ptr(bt.bn.shift),
+                                   C.ptr(bt.bn.sums) if sm else None, C.ptr(mb.weight) if sm else None,
+                                   C.ptr(mb.bias) if sm else None,
+                                   C.ptr(y.t), C.ptr(bnrec.sums) if (want_stats and sm) else None,
+                                   C.ptr(it.act.t), C.ptr(x.t)))
+            self.n_fused_sums += 1
+            stats_slot = 8
+        else:
+            stats_slot = 6
+            i = self.fwd.add(C.OP_CONV,
+                             ints=(self.dtid, x.N, x.H, x.W, cin, Ho, Wo, crec.Cout_pad, ks, stride, 0,
+                                   1 if xin.relu else 0, 0, 1 if (want_stats and self.bn_sums) else 0),
+                             floats=((1.0 / xin.bn.count, m_in.eps) if sums_in else ()),
+                             ptrs=(C.ptr(x.t), C.ptr(crec.wf),
+                                   C.ptr(xin.bn.scale) if (xin.bn and not sums_in) else None,
+                                   C.ptr(xin.bn.shift) if (xin.bn and not sums_in) else None,
+                                   C.ptr(self.net.bias_pad[crec.prefix]) if bias is not None else None,
+                                   C.ptr(y.t), C.ptr(bnrec.sums) if (want_stats and self.bn_sums) else None,
+                                   None, None, None, None,
+                                   C.ptr(xin.bn.sums) if sums_in else None, C.ptr(m_in.weight) if sums_in else None,
+                                   C.ptr(m_in.bias) if sums_in else None))
         self.fwd.tags[i] = crec.prefix
         if want_stats and not self.bn_sums:
             self.max_stats = max(self.max_stats, tiles * 2 * crec.Cout_pad)
-            self._scratch(self.fwd, i, 6, 'stats')
+            self._scratch(self.fwd, i, stats_slot, 'stats')
         x.nuse += 1
         if bnrec is not None:
             y.bn = bnrec
@@ -318,6 +343,16 @@ class Plan(object):
         ints += [1 if t.relu else 0 for t in terms] + [0] * (4 - len(terms))
         ptrs = [C.ptr(out.t)]
         ptrs += [C.ptr(t.act.t) for t in terms] + [None] * (4 - len(terms))
+        # relu(bn(y) + identity) that closes a block: held back - if the very next op of this lane is the stride-1
+        # conv that reads it, that conv forms the sum itself (hrnet_conv2d_sum); any other op emits it first
+        bn_terms = [t for t in terms if t.bn is not None]
+        hold = (self.fuse_sums and len(terms) == 2 and list(shifts) == [0, 0] and relu_out and len(bn_terms) == 1
+                and not bn_terms[0].relu and all(t.bn is not None or not t.relu for t in terms)
+                and (not self.bn_sums or t0.C <= 768))
+        emit = self.fwd.add
+        if hold:
+            held = []
+            emit = lambda *a, **k: held.append((a, k))
         if self.bn_sums and any(t.bn for t in terms):
             import struct
             mode = sum(1 << k for k, t in enumerate(terms) if t.bn)
@@ -325,15 +360,30 @@ class Plan(object):
             ptrs += [C.ptr(t.bn.sums) if t.bn else None for t in terms] + [None] * (4 - len(terms))
             ptrs += [C.ptr(t.bn.mod.weight) if t.bn else None for t in terms] + [None] * (4 - len(terms))
             floats = [1.0 / t.bn.count if t.bn else 0.0 for t in terms] + [0.0] * (4 - len(terms))
-            self.fwd.add(C.OP_SUM_TERMS, ints=ints, floats=floats, ptrs=ptrs)
+            emit(C.OP_SUM_TERMS, ints=ints, floats=floats, ptrs=ptrs)
         else:
             ptrs += [C.ptr(t.bn.scale) if t.bn else None for t in terms] + [None] * (4 - len(terms))
             ptrs += [C.ptr(t.bn.shift) if t.bn else None for t in terms] + [None] * (4 - len(terms))
-            self.fwd.add(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
+            emit(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
+        if hold:
+            self._flush_pending_sum()
+            self._pending_sum = dict(out=out, lane=self.fwd.lane, op=held[0], bn_term=bn_terms[0],
+                                     id_term=next(t for t in terms if t.bn is None))
         for t in terms:
             t.act.nuse += 1
         self._tape(('sum', list(terms), list(shifts), relu_out, out))
         return Val(out)
+
+    def _flush_pending_sum(self):
+        """emit the held-back residual sum as its own launch (its consumer was not a fusable conv)"""
+        ps = self._pending_sum
+        if ps is not None:
+            self._pending_sum = None
+            a, k = ps['op']
+            keep = self.fwd.lane
+            self.fwd.lane = ps['lane']
+            self.fwd.add(*a, **k)
+            self.fwd.lane = keep
 
     def bilinear_cat(self, vals, name, align=False):
         a0 = vals[0].act
@@ -357,6 +407,13 @@ class Plan(object):
         # BatchNorm coefficient buffers (scale/shift/mean/invstd/coef) belong to the PLAN: two plans of one net
         # can be in flight at once (hipnet.net.HipNet.plan), and each backward needs its own forward's statistics
         self.bns = {name: BNRec(name, rec.mod, self.dev) for name, rec in net.bns.items()}
+        # residual sums fused into the conv that reads them (hrnet_conv2d_sum): HRNET_FUSE_SUM=0 turns it off.
+        # Training only: 18.75 vs 18.92 ms/step; an eval pass is faster with the separate sum kernels (5.25 vs
+        # 5.36 ms: the two-tensor prologue re-reads two halos and lengthens the latency-bound conv launches)
+        self.fuse_sums = self.training and os.environ.get('HRNET_FUSE_SUM', '1') != '0'
+        self._pending_sum = None
+        self.n_fused_sums = 0
+        self.fwd.before_add = self._flush_pending_sum
         # Consumer-side BatchNorm (training): producers add their batch sums into 8 partial copies per BatchNorm with
         # float atomics, forward consumers build scale/shift from them on the fly, and ONE table-driven launch at the
         # end of the pass fills the arrays the backward pass reads and updates the running statistics - instead of a
@@ -436,6 +493,8 @@ class Plan(object):
                                      ptrs=(C.ptr(inter.act.t), None))
         if self.bn_sums and self.bn_finalize_list:
             self._add_bn_finalize_table()
+        self._flush_pending_sum()
+        self.fwd.before_add = None
         if self.need_grad:
             self._build_backward()
             if self.wlane:

@@ -63,7 +63,8 @@ enum {
   HR_OP_WGRAD_REDUCE_TABLE = 20, /* p[0] = device HrWredEnt table, i[0] = n, i[1] = total blocks */
   HR_OP_BWD_FUSED = 21,    /* hrnet_conv3x3_bwd_fused */
   HR_OP_BN_FINALIZE_TABLE = 22, /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
-  HR_OP_BWD_PW = 23        /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
+  HR_OP_BWD_PW = 23,       /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
+  HR_OP_CONV_SUM = 24      /* hrnet_conv2d_sum */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -291,6 +292,20 @@ int hrnet_conv2d_bnref(int dtype, const void* x, const void* w, const float* in_
                        const float* in_beta, float in_inv_count, float in_eps, const float* bias, void* y,
                        float* out_sums, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride,
                        int in_relu, hr_stream_t stream);
+/*
+ * Forward conv (3x3 or 1x1, stride 1) whose input is the residual sum that closes the previous block, formed in
+ * the conv's own prologue: a = relu(bn(x) + x2) with bn given as scale/shift arrays OR as batch sums + gamma/beta
+ * (as hrnet_conv2d_bnref), y = conv(a) (+ statistics of y: rows, or sums[8][2][Cout] when stats_atomic), and `side`
+ * = a, written once per pixel - the tensor the next residual add and the backward pass read. Replaces
+ * hrnet_sum_terms(relu(bn(x) + x2)) followed by hrnet_conv2d: one launch and one tensor read less
+ * (pose_hrnet.py:54-55 + :44 of the next BasicBlock; :95-96 + :79 for Bottlenecks).
+ *   x, x2, side [N,H,W,Cin]; y [N,H,W,Cout]; stats may be NULL (eval mode).
+ */
+int hrnet_conv2d_sum(int dtype, const void* x, const void* x2, const void* w, const float* in_scale,
+                     const float* in_shift, const float* in_sums, const float* in_gamma, const float* in_beta,
+                     float in_inv_count, float in_eps, void* side, void* y, float* stats, int stats_atomic, int N,
+                     int H, int W, int Cin, int Cout, int ks, hr_stream_t stream);
+
 typedef struct HrBnEnt {
   const float* sums;   /* [8][2][C]; NULL: eval mode - scale/shift from running_mean/var, nothing else written */
   const float* gamma;

@@ -16,7 +16,7 @@ def canon(name):
         ints = re.findall(r'Li(\d+)E', name) if name.startswith('_ZN') else [q.strip() for q in name[name.index('<') + 1:name.rindex('>')].split(',')]
         return '|'.join(['bwd_pw'] + ints)
     kind = ('conv' if 'conv_kernel' in name else 'conv_bs' if 'conv_bs_kernel' in name else
-            'conv_fwd' if 'conv_fwd_kernel' in name else 'conv_fwdb' if 'conv_fwdb_kernel' in name else 'conv_dg' if 'conv_dg_kernel' in name else
+            'conv_fwd' if 'conv_fwd_kernel' in name else 'conv_fwdb' if 'conv_fwdb_kernel' in name else 'conv_fwds' if 'conv_fwds_kernel' in name else 'conv_dg' if 'conv_dg_kernel' in name else
             'wgrad' if 'wgrad_kernel' in name else None)
     if kind is None:
         m = re.search(r'(\w+_kernel)', name)

@@ -127,6 +127,10 @@ def test_fp32_training_step_b40_256_on_the_multi_tile_walk(b40):
     walked = total = 0
     for prog in (plan.fwd, plan.bwd):
         for op in prog.ops:
+            if int(op.kind) == C.OP_CONV_SUM:      # conv with the residual sum in its prologue: same tile walk
+                C.call('hrnet_conv_tile_walk', op.i[1], op.i[2], op.i[3], op.i[5], op.i[6], 1, 0, 0, out)
+                total += 1
+                walked += out[3] >= 2
             if int(op.kind) == C.OP_CONV:
                 s2d = 1 if (op.i[10] and not op.p[2] and not op.p[4]) else 0
                 C.call('hrnet_conv_tile_walk', op.i[1], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
@@ -275,6 +279,8 @@ def _written(op, C):
     k = int(op.kind)
     if k == C.OP_CONV:
         return [(op.p[5], True)] + ([(op.p[6], False)] if op.p[7] else [])       # + backward-statistics rows
+    if k == C.OP_CONV_SUM:
+        return [(op.p[10], True), (op.p[7], True)]        # the residual sum written on the side + the conv output
     if k in (C.OP_SUM_TERMS, C.OP_BILINEAR_CAT):
         return [(op.p[0], True)]
     if k == C.OP_IM2COL_STEM or k == C.OP_NCHW_TO_NHWC:

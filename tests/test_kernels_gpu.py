@@ -240,6 +240,64 @@ def test_bn_finalize_train_and_eval(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(3, 20, 24, 32, 32, 3), (2, 8, 8, 64, 64, 3), (2, 16, 16, 128, 128, 3), (2, 16, 16, 256, 64, 1),
+                                   (40, 64, 64, 32, 32, 3), (2, 9, 7, 48, 48, 3)])
+@pytest.mark.parametrize('mode', ['affine', 'sums'])
+def test_conv_with_the_residual_sum_in_its_prologue(dtype, shape, mode):
+    """hrnet_conv2d_sum: a = relu(bn(x) + x2) formed while staging, y = conv(a) with its batch statistics, and a
+    written out once per pixel - against hrnet_sum_terms followed by hrnet_conv2d on the device (same arithmetic:
+    identical `side`, y within rounding order) and against torch (pose_hrnet.py:54-55 + :44 of the next block)."""
+    import ctypes
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cin, Cout, ks = shape
+    g = torch.Generator().manual_seed(5 + Cin + Cout + N + ks)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    x2 = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks), dtype)
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.rand(Cin, generator=g) - 0.5
+    d = hh.DEV
+    cnt = float(N * H * W)
+    mean = x.mean((0, 2, 3))
+    var = x.var((0, 2, 3), unbiased=False)
+    sc = gamma / torch.sqrt(var + 1e-5)
+    sh = beta - mean * sc
+    a_ref = _q(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + x2), dtype)
+    y_ref = F.conv2d(a_ref, w, None, padding=ks // 2)
+    xd, x2d = hh.nhwc(x, dtype), hh.nhwc(x2, dtype)
+    wp, _, _ = hh.pack_weights(w, dtype)
+    side = torch.full((N, H, W, Cin), float('nan'), dtype=dtype, device=d)
+    y = torch.full((N, H, W, Cout), float('nan'), dtype=dtype, device=d)
+    osums = torch.zeros(8, 2, Cout, device=d)
+    scd, shd, gd, bd = sc.to(d), sh.to(d), gamma.to(d), beta.to(d)
+    sums = torch.zeros(8, 2, Cin, device=d)
+    sums[3, 0] = (x.double().sum((0, 2, 3))).float().to(d)
+    sums[5, 1] = ((x.double() ** 2).sum((0, 2, 3))).float().to(d)
+    if mode == 'affine':
+        C.call('hrnet_conv2d_sum', hh.dt_id(dtype), xd.data_ptr(), x2d.data_ptr(), wp.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+               None, None, None, 0.0, 0.0, side.data_ptr(), y.data_ptr(), osums.data_ptr(), 1, N, H, W, Cin, Cout, ks, C.stream_ptr())
+    else:
+        C.call('hrnet_conv2d_sum', hh.dt_id(dtype), xd.data_ptr(), x2d.data_ptr(), wp.data_ptr(), None, None,
+               sums.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1.0 / cnt, 1e-5, side.data_ptr(), y.data_ptr(), osums.data_ptr(), 1,
+               N, H, W, Cin, Cout, ks, C.stream_ptr())
+    a_got = hh.from_nhwc(side)
+    assert not torch.isnan(a_got).any() and not torch.isnan(y.float()).any()
+    tol = TOL[dtype] if mode == 'affine' else 2 * TOL[dtype] + (0 if dtype == torch.float32 else 1e-2)
+    assert hh.rel_err(a_got, a_ref) <= (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+    assert hh.rel_err(hh.from_nhwc(y), y_ref) <= tol
+    s1 = osums.double().sum(0).cpu()
+    assert hh.rel_err(s1[0], y_ref.double().sum((0, 2, 3))) <= 5 * tol + 1e-3
+    assert hh.rel_err(s1[1], (y_ref.double() ** 2).sum((0, 2, 3))) <= 5 * tol
+    if mode == 'affine':
+        # the unfused pair on the device: the same sum values bit for bit
+        out = torch.empty(N, H, W, Cin, dtype=dtype, device=d)
+        C.call('hrnet_sum_terms', hh.dt_id(dtype), out.data_ptr(), N, H, W, Cin, 2, hh.ptr_array([xd, x2d]),
+               hh.ptr_array([scd, None]), hh.ptr_array([shd, None]), hh.int_array([0, 0]), hh.int_array([0, 0]), 1,
+               C.stream_ptr())
+        assert torch.equal(out.float().cpu(), side.float().cpu())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_pack_table_matches_the_per_layer_pack(dtype):
     """hrnet_pack_weights_table (every conv of the network in one launch, rows staged through LDS) against
     hrnet_pack_weights layer by layer, bit for bit: forward layout, transposed/flipped input-gradient layout and
