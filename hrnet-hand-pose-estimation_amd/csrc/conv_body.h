@@ -168,17 +168,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   // a backward-statistics launch is an input-gradient conv: raw dY in, no bias (checked by the launcher)
   const bool from_sums = TAB ? a.in_sums != nullptr : false;
   const bool has_affine = RAW_IN ? false : (a.in_scale != nullptr || from_sums);
-  if constexpr (TAB) {
-    if (from_sums) {
-      for (int c = threadIdx.x; c < a.Cin; c += 256) {
-        float sc_, sh_, m_, r_, v_;
-        hr_bn_from_sums(a.in_sums, a.Cin, c, a.in_inv_count, a.in_eps, a.in_gamma[c], a.in_beta[c], sc_, sh_, m_, r_, v_);
-        bntab[c] = sc_;
-        bntab[a.Cin + c] = sh_;
+  // (the table is built AFTER the first stage's global loads are issued - its 16 loads per channel and the f64
+  // arithmetic run under their latency - and read when that stage is written to LDS)
+  auto build_bntab = [&]() {
+    if constexpr (TAB) {
+      if (from_sums) {
+        for (int c = threadIdx.x; c < a.Cin; c += 256) {
+          float sc_, sh_, m_, r_, v_;
+          hr_bn_from_sums(a.in_sums, a.Cin, c, a.in_inv_count, a.in_eps, a.in_gamma[c], a.in_beta[c], sc_, sh_, m_, r_, v_);
+          bntab[c] = sc_;
+          bntab[a.Cin + c] = sh_;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-  }
+  };
   const bool in_relu = RAW_IN ? false : a.in_relu != 0;
   constexpr bool FWDLIKE = MODE == CONV_FWD || MODE == CONV_FWDB || MODE == CONV_FWDS;
   const bool A_UPZ = FWDLIKE ? false : a.upz != 0;
@@ -284,19 +288,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int iy0 = ty * TIH * SST - PAD, ix0 = tx * TIW * SST - PAD;
     const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
-    if (has_affine && cvalid) {
-      if (from_sums) {
+    if (has_affine && cvalid && !from_sums) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          sc[j] = bntab[c + j];
-          sh[j] = bntab[a.Cin + c + j];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          sc[j] = a.in_scale[c + j];
-          sh[j] = a.in_shift[c + j];
-        }
+      for (int j = 0; j < VEC; ++j) {
+        sc[j] = a.in_scale[c + j];
+        sh[j] = a.in_shift[c + j];
       }
     }
     xok = 0;
@@ -372,6 +368,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   };
 
   auto store_stage = [&](int s) {
+    if constexpr (TAB) {
+      if (from_sums) {      // this stage's channel chunk out of the on-the-fly table
+        const int c = (s % nch) * C::KC + v * VEC;
+        if (c < a.Cin) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            sc[j] = bntab[c + j];
+            sh[j] = bntab[a.Cin + c + j];
+          }
+        }
+      }
+    }
     if constexpr (X2) {
       // a = relu(scale*x + shift + x2), rounded once: what goes to LDS IS what goes to `side`
 #pragma unroll
@@ -476,6 +484,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
 #endif
   STAMP();
   if (nstage > 0) load_stage(0);
+  build_bntab();
   STAMP();
   // tile loop outside, K-chunk loop inside: the accumulators live in one tile iteration (declared,
   // zeroed, accumulated in place, stored). A flat stage loop with a conditional reset made hipcc shuffle
