@@ -291,6 +291,35 @@ def test_atomic_batch_statistics_agree_with_the_deterministic_form(monkeypatch):
             np.testing.assert_allclose(a[2][k].numpy(), v.numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
 
 
+def test_residual_sums_fused_into_the_next_conv_change_nothing(monkeypatch):
+    """hrnet_conv2d_sum (the residual sum formed in the prologue of the conv that reads it) against the separate
+    hrnet_sum_terms launch: the sum values are bit-identical and the conv sees the same operands in the same
+    order, so with ordered batch statistics (HRNET_DETERMINISTIC=1) the whole step is bit-identical."""
+    from hipnet import synth
+    from hipnet import _capi as C
+    from core.loss import HeatmapLoss
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1')
+    b = synth.rhd_batch(4, seed=17, img_h=128, img_w=128)
+    x, gt = torch.from_numpy(b['imgs']).cuda(), torch.from_numpy(b['heatmaps']).cuda()
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HRNET_FUSE_SUM', mode)
+        model, _, _ = make_model('bf16', 7)
+        model.train()
+        hm, inter = model(x)
+        HeatmapLoss()(hm, gt).backward()
+        plan = model.hip().all_plans()[0]
+        n = sum(1 for o in plan.fwd.ops if int(o.kind) == C.OP_CONV_SUM)
+        assert n == plan.n_fused_sums and (n >= 70 if mode == '1' else n == 0), n
+        res[mode] = (hm.detach().cpu(), inter.detach().cpu(), model.hip().flat_g.detach().cpu().clone(),
+                     {k: v.cpu().clone() for k, v in model.state_dict().items() if 'running' in k})
+    a, bb = res['1'], res['0']
+    assert torch.equal(a[0], bb[0]) and torch.equal(a[1], bb[1])
+    assert torch.equal(a[2], bb[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], bb[3][k]), k
+
+
 def test_optimizer_step_changes_output_and_inter_feat_gradient_path():
     from hipnet import synth
     model, _, _ = make_model('fp32', 4)
