@@ -608,7 +608,8 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   // (64x64 maps: 2048 workgroup-tiles at batch 64) sits in the single-lane tail of the backward pass and takes
   // every CU (165 us on 128 CUs)
   static const int big = getenv("HRNET_FUSED_CUS_BIG") ? atoi(getenv("HRNET_FUSED_CUS_BIG")) : 256;
-  int ns = ((long long)tiles * ncb >= 2048 ? big : cus) * c.per_cu / ncb;
+  static const int cus128 = getenv("HRNET_FUSED_CUS_128") ? atoi(getenv("HRNET_FUSED_CUS_128")) : 128;   // (measurement)
+  int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb >= 2048 ? big : cus) * c.per_cu / ncb;
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   // even walks: every split takes the same number of tiles when possible
