@@ -209,4 +209,7 @@ int hr_launch_wgrad_reduce_table(const HrOp& op, hipStream_t s);
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s);
 int hr_launch_bwd_pw(const HrOp& op, hipStream_t s);
 int hr_launch_conv_sum(const HrOp& op, hipStream_t s);
+int hr_gemm_pw_supported(int dtype, int Cin, int Cout);
+int hr_gemm_pw(const void* x, const void* w, const float* bias, void* y, float* sums, long long pixels, int Cin,
+               int Cout, hipStream_t s);
 int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s);

@@ -77,6 +77,10 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   const int mode = conv_mode(a, op.i[11] != 0);
   HR_REQUIRE(!a.in_sums || mode == CONV_FWD || mode == CONV_FWDB,
              "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
+  // the GEMM-shaped head layer (and its input gradient): every output channel of a pixel block in one workgroup
+  if (ks == 1 && stride == 1 && !upz && !a.accumulate && !a.bs_y && !a.in_scale && !a.in_sums && !op.i[11] &&
+      (!a.stats || a.stats_atomic) && hr_gemm_pw_supported(dtype, Cin, Cout))
+    return hr_gemm_pw(a.x, a.w, a.bias, a.y, a.stats, (long long)N * H * W, Cin, Cout, s);
   // input gradient of a 3x3 stride-2 conv: the input-gradient bodies evaluate the four output parities
   // from the real dY tile (S2D, template stride 4); other modes read it as a zero-stuffed grid
   const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
@@ -230,6 +234,11 @@ extern "C" int hrnet_conv_mode(int bwdstats, int has_bias, int upz, int accumula
 // bench.py's per-kernel timings can be matched against rocprofv3's kernel trace).
 extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride,
                                       int upz, int mode, char* buf, int buflen) {
+  // (the head's 480 -> 480 layer and its input gradient run the GEMM kernel; in HRNET_DETERMINISTIC=1 mode the
+  // forward launch stays on the tile-walking body, which this name query cannot see)
+  if (ks == 1 && stride == 1 && !upz && hr_gemm_pw_supported(dtype, Cin, Cout) &&
+      (mode == CONV_FWD || mode == CONV_FWDB || mode == CONV_DG))
+    return snprintf(buf, buflen, "gemm_pw_kernel");
   const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
   const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS, s2d);
   static const int wp[8] = {4, 2, 2, 2, 2, 0, 4, 2}, wc[8] = {1, 2, 2, 2, 2, 0, 1, 2};

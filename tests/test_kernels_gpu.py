@@ -297,6 +297,46 @@ def test_conv_with_the_residual_sum_in_its_prologue(dtype, shape, mode):
         assert torch.equal(out.float().cpu(), side.float().cpu())
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 16, 480, 480), (1, 9, 7, 480, 480), (3, 8, 8, 256, 256), (2, 8, 8, 512, 512),
+                                   (1, 16, 16, 480, 256)])
+def test_head_gemm_forward_with_bias_and_statistics_and_input_gradient(shape):
+    """the GEMM kernel behind hrnet_conv2d for the head's 1x1 480 -> 480 layer (bf16): forward with bias and
+    atomically accumulated batch statistics (hrnet_conv2d_bnref), and the plain launch with the transposed
+    packed weights that is its input gradient (pose_hrnet.py:334-340 and its autograd)"""
+    hh = _h()
+    from hipnet import _capi as C
+    dtype = torch.bfloat16
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(3 + Cin + Cout + N)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin), dtype)
+    b = torch.randn(Cout, generator=g)
+    d = hh.DEV
+    xd = hh.nhwc(x, dtype)
+    wp, _, _ = hh.pack_weights(w, dtype)
+    y = torch.full((N, H, W, Cout), float('nan'), dtype=dtype, device=d)
+    sums = torch.zeros(8, 2, Cout, device=d)
+    bd = b.to(d)
+    C.call('hrnet_conv2d_bnref', hh.dt_id(dtype), xd.data_ptr(), wp.data_ptr(), None, None, None, 0.0, 0.0, bd.data_ptr(),
+           y.data_ptr(), sums.data_ptr(), N, H, W, Cin, H, W, Cout, 1, 1, 0, C.stream_ptr())
+    ref = F.conv2d(x, w, b)
+    got = hh.from_nhwc(y)
+    assert not torch.isnan(got).any()
+    assert hh.rel_err(got, ref) <= TOL[dtype]
+    s = sums.double().sum(0).cpu()
+    assert hh.rel_err(s[0], ref.double().sum((0, 2, 3))) <= 5 * TOL[dtype] + 1e-3
+    assert hh.rel_err(s[1], (ref.double() ** 2).sum((0, 2, 3))) <= 5 * TOL[dtype]
+    # input gradient: dx = dy * W as a 1x1 conv with the transposed packed weights, no bias, no statistics
+    dy = _q(torch.randn(N, Cout, H, W, generator=g), dtype)
+    wd, _, _ = hh.pack_weights(w, dtype, mode=1)
+    dx = torch.full((N, H, W, Cin), float('nan'), dtype=dtype, device=d)
+    dyd = hh.nhwc(dy, dtype)
+    C.call('hrnet_conv2d', hh.dt_id(dtype), dyd.data_ptr(), wd.data_ptr(), None, None, None, dx.data_ptr(), None,
+           N, H, W, Cout, H, W, Cin, 1, 1, 0, 0, 0, C.stream_ptr())
+    want = F.conv_transpose2d(dy, w)
+    assert hh.rel_err(hh.from_nhwc(dx), want) <= TOL[dtype]
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_pack_table_matches_the_per_layer_pack(dtype):
     """hrnet_pack_weights_table (every conv of the network in one launch, rows staged through LDS) against
