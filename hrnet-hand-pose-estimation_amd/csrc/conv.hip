@@ -46,7 +46,8 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "conv2d: empty shape");
   HR_REQUIRE(op.p[0] && op.p[1] && op.p[5], "conv2d: null tensor pointer");
   HR_REQUIRE((op.p[2] == nullptr) == (op.p[3] == nullptr), "conv2d: scale/shift must come together");
-  ConvArgs a;
+  ConvArgs a = {};
+  a.bs_store_masked = op.i[14];
   a.x = (const char*)op.p[0];
   a.w = (const char*)op.p[1];
   a.in_scale = (const float*)op.p[2];
@@ -68,6 +69,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
              "conv2d: input batch sums need gamma/beta, no scale/shift arrays, Cin <= %d", HR_CONV_MAXC);
   HR_REQUIRE(!a.in_sums || !a.bs_y, "conv2d: batch-sum input is for forward launches");
   HR_REQUIRE(!a.bs_y || a.stats, "conv2d: backward statistics need a rows buffer");
+  HR_REQUIRE(!a.bs_store_masked || a.bs_y, "conv2d: the masked store belongs to a backward-statistics launch");
   HR_REQUIRE(!a.bs_y || (!a.in_scale && !a.bias && !op.i[11]),
              "conv2d: backward statistics are for input-gradient launches (no input affine / ReLU / bias)");
   HR_REQUIRE((a.bs_scale == nullptr) == (a.bs_shift == nullptr), "conv2d: mask scale/shift must come together");

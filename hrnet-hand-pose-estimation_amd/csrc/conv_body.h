@@ -62,6 +62,9 @@ struct ConvArgs {
   // every staged tile are also written to `side`: the sum tensor the next residual add and the backward pass read.
   const char* x2;
   char* side;
+  // backward-statistics launches: store dz = v * [mask > 0] instead of v (the masked-gradient convention of the
+  // fused backward launches: the buffer then needs no separate mask pass)
+  int bs_store_masked;
 };
 
 constexpr int HR_CONV_MAXC = 768;   // channels of the on-the-fly coefficient table (w48 head: 720)
@@ -577,24 +580,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             s2[k] += vals[k] * vals[k];
           }
         }
+        // (accumulate) -> statistics -> store: the backward-statistics mode may store the MASKED gradient
+        if (A_ACC) {
 #pragma unroll
-        for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
-          if constexpr (C::LANE_C >= VEC) {
-            if (A_ACC) {
+          for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
+            if constexpr (C::LANE_C >= VEC) {
               float old[VEC];
               v16_unpack<T>(*(const V16*)(dst + k0 * sizeof(T)), old);
 #pragma unroll
               for (int j = 0; j < VEC; ++j) vals[k0 + j] += old[j];
-            }
-            *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
-          } else {
-            // LANE_C == 4 with bf16: one 8-byte store
-            if (A_ACC) {
+            } else {
               const bf16x4 old = *(const bf16x4*)dst;
               vals[0] += (float)old.x; vals[1] += (float)old.y; vals[2] += (float)old.z; vals[3] += (float)old.w;
             }
-            const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
-            *(bf16x4*)dst = o;
           }
         }
         if constexpr (BS) {
@@ -615,6 +613,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
             const float dz = (!masked || mv[k] > 0.f) ? vals[k] : 0.f;
             s1[k] += dz;
             s2[k] = fmaf(dz, yv[k], s2[k]);
+            if (a.bs_store_masked) vals[k] = dz;     // what is stored IS the next BatchNorm backward's dz
+          }
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < C::LANE_C; k0 += VEC) {
+          if constexpr (C::LANE_C >= VEC) {
+            *(V16*)(dst + k0 * sizeof(T)) = v16_pack<T>(vals + k0);
+          } else {
+            // LANE_C == 4 with bf16: one 8-byte store
+            const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
+            *(bf16x4*)dst = o;
           }
         }
       }

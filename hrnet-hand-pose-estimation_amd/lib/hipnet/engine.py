@@ -691,6 +691,7 @@ class Plan(object):
         first_fork = next((i for i, e in enumerate(self.tape) if e[0] == 'fork'), None)
         fused_at, fused_skip = self._find_fused_blocks(), set()
         self.n_fused_blocks = len(fused_at)
+        self._fused_out_ids = {id(self.tape[ti][4]) for ti in fused_at}     # block outputs a fused launch consumes
         for ti, (e, lane) in reversed(list(enumerate(zip(self.tape, self.tape_lanes)))):
             self.bwd.lane = lane
             if ti in fused_skip:
@@ -863,17 +864,25 @@ class Plan(object):
                             target = cand[0].act
                             ptrs[7] = C.ptr(target.t)
                             ptrs[8] = C.ptr(x.t) if relu_out else None
+                    store_masked = 0
                     if target is not None:
                         nrows = C.call('hrnet_conv_tiles_bwdstats', x.N, x.H, x.W, x.C, ks, stride)
                         rows = self._f32(nrows * 2 * x.C)
                         ptrs[6] = C.ptr(rows)
                         target.bwd_rows = (rows, nrows)
                         self.n_fused_bwdstats += 1
+                        if (target is not x and ptrs[8] is not None and id(x) in self._fused_out_ids
+                                and os.environ.get('HRNET_BS_STORE_MASKED', '1') != '0'):
+                            # x closes a block whose backward is a fused launch: this (last) contribution stores the
+                            # gradient already multiplied by x's ReLU mask - no separate mask pass over the tensor
+                            store_masked = 1
                     self.bwd.add(C.OP_CONV,
                                  ints=(self.dtid, y.N, y.H, y.W, y.C, x.H, x.W, x.C, ks, stride,
-                                       1 if stride == 2 else 0, 0, 1 if x.ginit else 0),
+                                       1 if stride == 2 else 0, 0, 1 if x.ginit else 0, 0, store_masked),
                                  ptrs=ptrs)
                     x.ginit = True
+                    if store_masked:
+                        x.gmasked = True
                 if lane == 0 and not in_region:
                     self._bucket_mark_after_conv(crec)
         if self.batch_wred:

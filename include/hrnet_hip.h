@@ -41,7 +41,8 @@ enum {
 
 /* ---- op kinds of a recorded program (hrnet_program_run) -------------------------------- */
 enum {
-  HR_OP_CONV = 1,          /* conv / dgrad (implicit GEMM, MFMA) */
+  HR_OP_CONV = 1,          /* conv / dgrad (implicit GEMM, MFMA); a backward-statistics op may set i[14] = 1: the
+                              stored gradient is dz = v * [mask > 0] (what the fused backward launches expect) */
   HR_OP_WGRAD = 2,         /* weight gradient partial slabs */
   HR_OP_WGRAD_REDUCE = 3,  /* slabs -> OIHW f32 gradient */
   HR_OP_BN_FINALIZE = 4,   /* stat partials -> scale/shift (+ running stats) */
