@@ -237,6 +237,7 @@ class Plan(object):
         # dependency-bound - and '1' is slower.
         wl = os.environ.get('HRNET_WLANE', '0')
         self.wlane = 4 if (self.nlanes > 1 and wl in ('1', '2')) else 0
+        self.defer_lanes = int(os.environ.get('HRNET_DEFER_LANES', '3'))      # side lanes the deferred weight gradients use
         self.wlane_all = wl == '1'
         self.streams = None
         self.gen = 0              # bumped by every forward run: a backward must see the generation it recorded
@@ -1161,7 +1162,9 @@ class Plan(object):
 
     def _emit_deferred_wgrads(self):
         """enqueue the recorded weight-gradient launches on the side lanes (largest first, least-loaded lane)"""
-        side = [l for l in range(1, self.nlanes)]
+        # the deferred launches are small grids (32-64 workgroups each): more of them in flight than the three
+        # branch lanes fill more of the chip beside the single-lane tail
+        side = [l for l in range(1, 1 + self.defer_lanes)]
         if not self._deferred or not side:
             return
         keep = self.bwd.lane
@@ -1246,7 +1249,8 @@ class Plan(object):
             # lane 0 = PyTorch's current stream. (Measured on MI355X: high-priority side streams made the
             # backward 2.5x slower, and a separate weight-gradient lane 7 % slower - its big grids take
             # CU slots from the critical path - so both stay off by default.)
-            self.streams = [None] + [torch.cuda.Stream(device=self.dev) for _ in range(self.nlanes)]
+            self.streams = [None] + [torch.cuda.Stream(device=self.dev)
+                                     for _ in range(max(self.nlanes, self.defer_lanes))]
         return self.streams
 
     # ---- execution --------------------------------------------------------------------------
