@@ -686,6 +686,9 @@ class Plan(object):
         tail_pixels = self.N * (self.H // 4) * (self.W // 4)
         self._defer_budget = float(os.environ.get('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
         self._defer_flops = 0.0
+        self.offload_wgrad = self.defer_wgrad and os.environ.get('HRNET_OFFLOAD_WGRAD', '1') != '0'
+        self._offload_rr = 0
+        self._offload_lanes = set()
         self._deferred = []
         self._deferred_lanes = []
         self.n_deferred_wgrads = 0
@@ -828,6 +831,16 @@ class Plan(object):
                     if deferred:
                         # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends
                         self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
+                    elif self.offload_wgrad and lane == 0 and not in_region:
+                        # a single-lane part of the pass (head, transition1, stem): its weight gradients are off the
+                        # dependency chain - they go to a side lane, which idles there (the head) or carries the
+                        # deferred launches (the tail); their gradient is complete at the end of the program
+                        l = 1 + self._offload_rr % max(1, self.nlanes - 1)
+                        self._offload_rr += 1
+                        self.bwd.sync(0, l)
+                        self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
+                        self._wred.setdefault(l, []).append(ent)
+                        self._offload_lanes.add(l)
                     else:
                         self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
                         self._wred.setdefault(self.bwd.lane, []).append(ent)
@@ -890,8 +903,9 @@ class Plan(object):
             for l in sorted(self._wred):
                 self._flush_wred(l)
             self.bwd.lane = 0
-            if self._deferred_lanes:
-                self.bwd.join(self._deferred_lanes)       # the deferred weight gradients (and their slab sums) are done
+            late = sorted(set(self._deferred_lanes) | self._offload_lanes)
+            if late:
+                self.bwd.join(late)       # the deferred / offloaded weight gradients (and their slab sums) are done
             self._upload_wred_tables()
 
     # ---- fused backward of a BasicBlock (conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU: pose_hrnet.py:41-57) ----
