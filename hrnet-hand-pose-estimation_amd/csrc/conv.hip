@@ -48,6 +48,9 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   HR_REQUIRE((op.p[2] == nullptr) == (op.p[3] == nullptr), "conv2d: scale/shift must come together");
   ConvArgs a = {};
   a.bs_store_masked = op.i[14];
+  a.in_dy = op.i[15]; a.in_dx = op.i[16];
+  HR_REQUIRE((a.in_dy == 0 && a.in_dx == 0) || (ks == 1 && stride == 1 && !upz && !op.p[7]),
+             "conv2d: a displaced input window belongs to a 1x1 stride-1 launch");
   a.x = (const char*)op.p[0];
   a.w = (const char*)op.p[1];
   a.in_scale = (const float*)op.p[2];
@@ -81,7 +84,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
              "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
   // the GEMM-shaped head layer (and its input gradient): every output channel of a pixel block in one workgroup
   if (ks == 1 && stride == 1 && !upz && !a.accumulate && !a.bs_y && !a.in_scale && !a.in_sums && !op.i[11] &&
-      (!a.stats || a.stats_atomic) && hr_gemm_pw_supported(dtype, Cin, Cout))
+      (!a.stats || a.stats_atomic) && !a.in_dy && !a.in_dx && hr_gemm_pw_supported(dtype, Cin, Cout))
     return hr_gemm_pw(a.x, a.w, a.bias, a.y, a.stats, (long long)N * H * W, Cin, Cout, s);
   // input gradient of a 3x3 stride-2 conv: the input-gradient bodies evaluate the four output parities
   // from the real dY tile (S2D, template stride 4); other modes read it as a zero-stuffed grid
@@ -176,6 +179,27 @@ extern "C" int hrnet_conv2d_sum(int dtype, const void* x, const void* x2, const 
   op.p[4] = (void*)in_sums; op.p[5] = (void*)in_gamma; op.p[6] = (void*)in_beta; op.p[7] = y; op.p[8] = stats;
   op.p[9] = (void*)x2; op.p[10] = side;
   return hr_launch_conv_sum(op, (hipStream_t)stream);
+}
+
+// y = conv3x3(x, dilation d, padding d): nine 1x1 launches over input windows displaced by ((r-1)d, (s-1)d), the
+// first overwriting y and the others accumulating (f32 accumulation inside a launch, y rounded between taps)
+extern "C" int hrnet_conv2d_dilated3x3(int dtype, const void* x, const void* w_taps, long long tap_stride_bytes,
+                                       void* y, int N, int H, int W, int Cin, int Cout, int dilation,
+                                       hr_stream_t stream) {
+  HR_REQUIRE(dilation >= 1 && w_taps && tap_stride_bytes > 0, "conv2d_dilated3x3: arguments");
+  for (int t = 0; t < 9; ++t) {
+    HrOp op = {};
+    op.kind = HR_OP_CONV;
+    const int iv[13] = {dtype, N, H, W, Cin, H, W, Cout, 1, 1, 0, 0, t > 0 ? 1 : 0};
+    for (int k = 0; k < 13; ++k) op.i[k] = iv[k];
+    op.i[15] = (t / 3 - 1) * dilation;
+    op.i[16] = (t % 3 - 1) * dilation;
+    op.p[0] = (void*)x;
+    op.p[1] = (void*)((const char*)w_taps + (size_t)t * tap_stride_bytes);
+    op.p[5] = y;
+    if (int e = hr_launch_conv(op, (hipStream_t)stream)) return e;
+  }
+  return 0;
 }
 
 extern "C" int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,

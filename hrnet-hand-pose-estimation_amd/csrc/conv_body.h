@@ -65,6 +65,9 @@ struct ConvArgs {
   // backward-statistics launches: store dz = v * [mask > 0] instead of v (the masked-gradient convention of the
   // fused backward launches: the buffer then needs no separate mask pass)
   int bs_store_masked;
+  // the staged input window is displaced by (in_dy, in_dx) pixels (zero outside the image): one tap of a dilated
+  // convolution run as a shifted 1x1 conv (hrnet_conv2d_dilated3x3)
+  int in_dy, in_dx;
 };
 
 constexpr int HR_CONV_MAXC = 768;   // channels of the on-the-fly coefficient table (w48 head: 720)
@@ -288,7 +291,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
     const int t = s / nch, ch = s - t * nch;
     const int n = __builtin_amdgcn_readfirstlane(cur_n), ty = __builtin_amdgcn_readfirstlane(cur_ty),
               tx = __builtin_amdgcn_readfirstlane(cur_tx);
-    const int iy0 = ty * TIH * SST - PAD, ix0 = tx * TIW * SST - PAD;
+    const int iy0 = ty * TIH * SST - PAD + a.in_dy, ix0 = tx * TIW * SST - PAD + a.in_dx;
     const int c = ch * C::KC + v * VEC;
     const bool cvalid = c < a.Cin;
     if (has_affine && cvalid && !from_sums) {

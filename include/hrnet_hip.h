@@ -113,6 +113,16 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                  int in_relu, int accumulate, hr_stream_t stream);
 
 /*
+ * 3x3 convolution with dilation d and padding d (the offset-generating convs of pose_hrnet_PoseAggr,
+ * lib/models/pose_hrnet_PoseAggr.py:497-506: dilations 3, 6, 12, 18, 24; a halo of d pixels does not fit the tiled
+ * conv body): nine 1x1 launches over input windows displaced by ((r-1)d, (s-1)d), accumulating into y.
+ *   w_taps: nine packed 1x1 weight matrices [Cout][Cin] (hrnet_pack_weights mode 0 of w[:, :, r, s]), tap t = 3r+s
+ *   at w_taps + t * tap_stride_bytes. No bias / BatchNorm prologue; y is rounded to `dtype` between taps.
+ */
+int hrnet_conv2d_dilated3x3(int dtype, const void* x, const void* w_taps, long long tap_stride_bytes, void* y,
+                            int N, int H, int W, int Cin, int Cout, int dilation, hr_stream_t stream);
+
+/*
  * Input-gradient convolution that also gathers the statistics of the BatchNorm backward pass of
  * its output (autograd of pose_hrnet.py:43-57 - the reduction half of native_batch_norm_backward):
  * y (overwritten or accumulated) is the gradient v of an activation; stats rows receive

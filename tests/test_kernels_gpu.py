@@ -338,6 +338,31 @@ def test_head_gemm_forward_with_bias_and_statistics_and_input_gradient(shape):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 64, 128, 384, 3), (1, 64, 64, 128, 384, 24), (2, 20, 28, 32, 48, 6), (1, 16, 16, 64, 32, 18)])
+def test_dilated_conv_as_nine_displaced_pointwise_launches(dtype, shape):
+    """hrnet_conv2d_dilated3x3 against F.conv2d(dilation=d, padding=d): the offset-generating convs of
+    pose_hrnet_PoseAggr (reference lib/models/pose_hrnet_PoseAggr.py:497-506; 128 -> 21*18 channels, d = 3..24,
+    including d larger than the map borders reach)"""
+    hh = _h()
+    from hipnet import _capi as C
+    N, H, W, Cin, Cout, dil = shape
+    g = torch.Generator().manual_seed(9 + Cin + Cout + dil)
+    x = _q(torch.randn(N, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9), dtype)
+    ref = F.conv2d(x, w, None, padding=dil, dilation=dil)
+    xd = hh.nhwc(x, dtype)
+    taps = [hh.pack_weights(w[:, :, t // 3, t % 3].reshape(Cout, Cin, 1, 1).contiguous(), dtype)[0] for t in range(9)]
+    wt = torch.stack(taps)                       # [9][Cout_pad * Cin_pad]
+    y = torch.full((N, H, W, Cout), float('nan'), dtype=dtype, device=hh.DEV)
+    C.call('hrnet_conv2d_dilated3x3', hh.dt_id(dtype), xd.data_ptr(), wt.data_ptr(), wt.stride(0) * wt.element_size(),
+           y.data_ptr(), N, H, W, Cin, Cout, dil, C.stream_ptr())
+    got = hh.from_nhwc(y)
+    assert not torch.isnan(got).any()
+    # bf16: the running sum is rounded after every tap (nine roundings of y)
+    assert hh.rel_err(got, ref) <= (TOL[dtype] if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_pack_table_matches_the_per_layer_pack(dtype):
     """hrnet_pack_weights_table (every conv of the network in one launch, rows staged through LDS) against
     hrnet_pack_weights layer by layer, bit for bit: forward layout, transposed/flipped input-gradient layout and
