@@ -945,7 +945,40 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(V16* p, long long n16, c
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
 
+struct LinArgs {
+  const float* src[8];
+  float coef[8];
+  float* out;
+  long long n;
+  int k;
+};
+// out[i] = sum_j coef[j] * src[j][i] over f32 NCHW heat maps: the frame differences and the temporal aggregation
+// of pose_hrnet_PoseAggr (reference lib/models/pose_hrnet_PoseAggr.py:612-640)
+__global__ __launch_bounds__(256) void lincomb_f32_kernel(LinArgs a) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.k) s = fmaf(a.coef[j], a.src[j][i], s);
+    a.out[i] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int hrnet_lincomb_f32(float* out, long long n, int k, const float* const* srcs, const float* coefs,
+                                 hr_stream_t stream) {
+  HR_REQUIRE(out && srcs && coefs && n > 0 && k >= 1 && k <= 8, "lincomb_f32: arguments");
+  LinArgs a;
+  for (int j = 0; j < 8; ++j) {
+    a.src[j] = j < k ? srcs[j] : nullptr;
+    a.coef[j] = j < k ? coefs[j] : 0.f;
+    HR_REQUIRE(j >= k || a.src[j], "lincomb_f32: null source %d", j);
+  }
+  a.out = out; a.n = n; a.k = k;
+  hipLaunchKernelGGL(lincomb_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a);
+  return hr_check_launch("lincomb_f32");
+}
 
 // =========================================================================================
 // launchers

@@ -71,6 +71,7 @@ _SIGS = {
     'hrnet_conv2d_bwdstats': [_c_int] + [_c_vp] * 8 + [_c_int] * 11 + [_c_vp],
     'hrnet_conv2d_bnref': [_c_int] + [_c_vp] * 5 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 10 + [_c_vp],
     'hrnet_bn_finalize_table': [_c_vp, _c_int, _c_int, _c_vp],
+    'hrnet_lincomb_f32': [_c_vp, _c_i64, _c_int, _pp, ctypes.POINTER(ctypes.c_float), _c_vp],
     'hrnet_conv2d_dilated3x3': [_c_int, _c_vp, _c_vp, _c_i64, _c_vp] + [_c_int] * 6 + [_c_vp],
     'hrnet_conv2d_sum': [_c_int] + [_c_vp] * 8 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     'hrnet_sum_terms_bnref': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_int, ctypes.POINTER(ctypes.c_float), _c_float, _c_vp],

@@ -112,6 +112,12 @@ int hrnet_conv2d(int dtype, const void* x, const void* w, const float* in_scale,
                  int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, int upz,
                  int in_relu, int accumulate, hr_stream_t stream);
 
+/* out[i] = sum_{j<k} coefs[j] * srcs[j][i], f32, k <= 8 (host arrays of k device pointers / k coefficients): the
+ * frame differences and the weighted temporal aggregation of pose_hrnet_PoseAggr
+ * (lib/models/pose_hrnet_PoseAggr.py:612-640) */
+int hrnet_lincomb_f32(float* out, long long n, int k, const float* const* srcs, const float* coefs,
+                      hr_stream_t stream);
+
 /*
  * 3x3 convolution with dilation d and padding d (the offset-generating convs of pose_hrnet_PoseAggr,
  * lib/models/pose_hrnet_PoseAggr.py:497-506: dilations 3, 6, 12, 18, 24; a halo of d pixels does not fit the tiled
