@@ -94,6 +94,33 @@ def test_softmax_variant_module_surface():
     assert not pose_hrnet_softmax.get_pose_net(cfg, is_train=False).trainable_temp.requires_grad
 
 
+def test_poseaggr_variant_module_surface():
+    """pose_hrnet_PoseAggr (reference lib/models/pose_hrnet_PoseAggr.py:286-372): the softmax variant's keys, then the
+    offset-feature chain (first block 21 -> 128 with a 1x1 conv + BatchNorm on the identity, 19 more of 128), five
+    dilated offset convs (128 -> 21*2*9) and five deformable convs (weight, bias) - 1840 + 261 keys"""
+    from config import get_cfg_defaults
+    from models import pose_hrnet_PoseAggr
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml'))
+    m = eval('pose_hrnet_PoseAggr.get_pose_net')(cfg, is_train=False)
+    sd = m.state_dict()
+    keys = list(sd.keys())
+    assert keys[0] == 'trainable_temp' and len(keys) == 1840 + 261
+    assert keys[1840] == 'offset_feats.0.conv1.weight' and keys[-1] == 'deform_conv5.bias'
+    assert tuple(sd['offset_feats.0.conv1.weight'].shape) == (128, 21, 3, 3)
+    assert tuple(sd['offset_feats.0.downsample.0.weight'].shape) == (128, 21, 1, 1)
+    assert tuple(sd['offset_feats.19.conv2.weight'].shape) == (128, 128, 3, 3)
+    for k, d in enumerate((3, 6, 12, 18, 24), 1):
+        conv = getattr(m, 'offsets{}'.format(k))
+        assert tuple(conv.weight.shape) == (378, 128, 3, 3) and conv.dilation == (d, d) and conv.padding == (d, d)
+        dcn = getattr(m, 'deform_conv{}'.format(k))
+        assert tuple(dcn.weight.shape) == (21, 21, 3, 3) and dcn.dilation == (d, d) and dcn.deformable_groups == 21
+    # without warping at test time the model is the plain softmax variant (reference :611)
+    cfg.MODEL.USE_WARPING_TEST = False
+    plain = pose_hrnet_PoseAggr.get_pose_net(cfg, is_train=False)
+    assert len(plain.state_dict()) == 1840 and not plain.flag
+
+
 def test_init_weights_follows_reference_distribution():
     from config import get_cfg_defaults
     from models import pose_hrnet
