@@ -13,9 +13,15 @@ pose_hrnet_softmax produce the per-frame heat-map logits; then (reference :612-6
 
 every step a HIP launch through the C ABI: hrnet_lincomb_f32, hrnet_conv2d (+ BatchNorm prologues from the running
 statistics), hrnet_sum_terms, hrnet_conv2d_dilated3x3, hrnet_deform_conv_forward, hrnet_spatial_softmax_fwd. The head
-runs op by op (it is not part of the recorded programs). Training through the aggregation head
-(`USE_WARPING_TRAIN`: the reference freezes the backbone and trains offset_feats / offsets / deform convs) is not
-built: forward raises in training mode when the flag is set.
+runs op by op (it is not part of the recorded programs).
+
+TRAINING (`USE_WARPING_TRAIN`, reference :703-733): the reference freezes the backbone and trains offset_feats, the
+offset convs and the deformable convs. Here the backbone runs its recorded training-mode forward without a backward
+program (batch statistics, running statistics updated, no gradient - as with the reference's frozen parameters,
+whose only gradient consumer would be the backbone itself), and the head runs as op-by-op autograd layers
+(hipnet/eager.py: ConvBN, AddReLU, DilatedConv, LinComb + the deformable-conv and softmax Functions), each forward
+and backward a HIP launch. The head's gradients arrive in `param.grad` like any autograd gradient (use a torch
+optimiser over the head's parameters).
 
 state_dict(): the reference's keys in the reference's order - trainable_temp, backbone, offset_feats.{0..19},
 offsets1..5, deform_conv1..5 (weight, bias).
@@ -27,6 +33,7 @@ import torch.nn as nn
 
 from deformable_conv import DeformConv
 from hipnet import _capi as C
+from hipnet import eager as E
 from models.pose_hrnet import BN_MOMENTUM, BasicBlock, Bottleneck, HighResolutionModule, _Unit, blocks_dict  # noqa: F401
 from models.pose_hrnet_softmax import PoseHighResolutionNet as _SoftmaxNet
 from models.pose_hrnet_softmax import _SpatialSoftmax
@@ -150,16 +157,42 @@ class PoseHighResolutionNet(_SoftmaxNet):
         del per
         return out
 
+    def _aggregate_train(self, x, net):
+        """the same head as autograd layers over the C ABI (training-mode BatchNorm); x: (5B, nj, H, W) logits, no grad"""
+        T, nj, H, W = x.shape
+        if T % 5:
+            raise ValueError('pose_hrnet_PoseAggr expects 5 frames per sample (batch {} is not a multiple of 5)'.format(T))
+        B = T // 5
+        tdt = net.compute_dtype
+        xs = [x[g * B:(g + 1) * B] for g in range(5)]
+        diff = torch.empty_like(x)
+        for g in range(5):
+            _lincomb(diff[g * B:(g + 1) * B], [xs[2], xs[g]], [1.0, -1.0])
+        cur = E.ToNHWC.apply(diff, net.convs['offset_feats.0.conv1'].Cin_pad, tdt)
+        for unit in self.offset_feats:
+            cur = E.basic_block(cur, unit)
+        warped = []
+        for k, d in enumerate(self.dilation_rates, 1):
+            off = E.ToNCHW.apply(E.DilatedConv.apply(cur, getattr(self, 'offsets{}'.format(k)).weight, d), nj * 18)
+            warped.append(getattr(self, 'deform_conv{}'.format(k))(x, off))
+        w = E.LinComb.apply([0.2] * len(warped), *warped)
+        return E.LinComb.apply(list(FRAME_WEIGHTS), *[w[g * B:(g + 1) * B] for g in range(5)])
+
     def forward(self, x):
         warping = (self.training and self.use_warping_train) or (not self.training and self.use_warping_test)   # :611
         if not (warping and self.flag):
             return _SoftmaxNet.forward(self, x)
-        if self.training:
-            raise NotImplementedError('pose_hrnet_PoseAggr: training through the aggregation head (USE_WARPING_TRAIN) '
-                                      'is not built on the HIP path; model.eval() runs the aggregation forward')
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise RuntimeError('pose_hrnet_PoseAggr: input must be a tensor on the HIP device (.cuda()); no CPU path')
         net = self.hip()
+        if self.training and torch.is_grad_enabled():
+            with torch.no_grad():
+                logits, _, _ = net.forward(x.contiguous().float(), training=True, need_grad=False)
+            agg = self._aggregate_train(logits.contiguous(), net)
+            return _SpatialSoftmax.apply(agg, self.trainable_temp), self.trainable_temp
+        if self.training:
+            raise NotImplementedError('pose_hrnet_PoseAggr: a training-mode pass without gradients (batch statistics in '
+                                      'the aggregation head, no autograd) is not built; use model.eval() for inference')
         with torch.no_grad():
             logits, _, plan = net.forward(x.contiguous().float(), training=False, need_grad=False)
             agg = self._aggregate(logits.contiguous(), net, plan)

@@ -14,30 +14,32 @@ from oracle import dcn_cpu
 FRAME_WEIGHTS = (0.1, 0.25, 0.3, 0.25, 0.1)      # prev2, prev1, current, next1, next2 (:640)
 
 
-def _bn(x, sd, p, eps=1e-5):
+def _bn(x, sd, p, training=False, eps=1e-5):
+    if training:      # batch statistics (the running statistics are not needed by the comparison)
+        return F.batch_norm(x, None, None, sd[p + '.weight'], sd[p + '.bias'], True, 0.0, eps)
     return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
                         False, 0.0, eps)
 
 
-def offset_feats(x, sd, nblocks=20):
-    """BasicBlock chain (pose_hrnet_PoseAggr.py:28-57 blocks), eval-mode BatchNorm"""
+def offset_feats(x, sd, nblocks=20, training=False):
+    """BasicBlock chain (pose_hrnet_PoseAggr.py:28-57 blocks)"""
     for k in range(nblocks):
         p = 'offset_feats.{}'.format(k)
-        out = F.relu(_bn(F.conv2d(x, sd[p + '.conv1.weight'], None, padding=1), sd, p + '.bn1'))
-        out = _bn(F.conv2d(out, sd[p + '.conv2.weight'], None, padding=1), sd, p + '.bn2')
+        out = F.relu(_bn(F.conv2d(x, sd[p + '.conv1.weight'], None, padding=1), sd, p + '.bn1', training))
+        out = _bn(F.conv2d(out, sd[p + '.conv2.weight'], None, padding=1), sd, p + '.bn2', training)
         res = x
         if (p + '.downsample.0.weight') in sd:
-            res = _bn(F.conv2d(x, sd[p + '.downsample.0.weight'], None), sd, p + '.downsample.1')
+            res = _bn(F.conv2d(x, sd[p + '.downsample.0.weight'], None), sd, p + '.downsample.1', training)
         x = F.relu(out + res)
     return x
 
 
-def aggregate(logits, sd, dilation_rates=(3, 6, 12, 18, 24)):
+def aggregate(logits, sd, dilation_rates=(3, 6, 12, 18, 24), training=False):
     """logits (5B, nj, H, W) ordered [prev2 | prev1 | current | next1 | next2] -> (B, nj, H, W)"""
     T, nj, H, W = logits.shape
     B = T // 5
     ref = logits[2 * B:3 * B].repeat(5, 1, 1, 1)
-    feats = offset_feats(ref - logits, sd)
+    feats = offset_feats(ref - logits, sd, training=training)
     warped = 0
     for k, d in enumerate(dilation_rates, 1):
         off = F.conv2d(feats, sd['offsets{}.weight'.format(k)], None, padding=d, dilation=d)

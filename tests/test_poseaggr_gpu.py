@@ -105,12 +105,59 @@ def test_aggregation_forward_matches_the_cpu_restatement(dtype, tol):
     assert err <= tol
 
 
-def test_training_through_the_aggregation_head_is_refused_clearly():
-    model, _, _ = _model('fp32')
+def test_training_through_the_aggregation_head_matches_cpu_autograd(monkeypatch):
+    """USE_WARPING_TRAIN: the backbone's recorded training-mode forward (no backward: the reference freezes it) and the
+    aggregation head as op-by-op autograd layers over the C ABI (hipnet/eager.py) - heat maps and the gradient of every
+    head parameter against torch autograd over oracle/poseaggr_cpu.py (float64, batch-statistics BatchNorm) fed with
+    the same logits. fp32 device path; 40 training-mode BatchNorm layers amplify rounding, so the
+    gradients are held to a direction / median band."""
+    from hipnet import synth
+    from oracle import poseaggr_cpu as O
+    monkeypatch.setenv('HRNET_DETERMINISTIC', '1')          # the two backbone passes below must give identical logits
+    model, cfg, _ = _model('fp32')
     model.train()
-    x = torch.zeros(5, 3, 64, 64, device='cuda')
-    with pytest.raises(NotImplementedError, match='USE_WARPING_TRAIN'):
-        model(x)
-    model.eval()
+    b = synth.rhd_batch(5, seed=8, img_h=128, img_w=128)               # one sample: 5 frames, 32x32 heat maps
+    x = torch.from_numpy(b['imgs']).cuda()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    heat, temp = model(x)
+    g = torch.Generator().manual_seed(2)
+    R = torch.randn(heat.shape, generator=g)
+    (heat * R.cuda()).sum().backward()
+    head = {k: p for k, p in model.named_parameters() if k.startswith(('offset_feats', 'offsets', 'deform_conv'))}
+    assert all(p.grad is not None for p in head.values())
+    assert model.conv1.weight.grad is None                    # the backbone got no gradient
+    assert int(model.offset_feats[3].bn1.num_batches_tracked) == 1      # training-mode BatchNorm in the head
+    # ---- oracle on the same logits (second backbone pass: same batch statistics, running statistics aside) ----
+    model.load_state_dict(sd0, strict=True)
+    model.invalidate_weights()
+    with torch.no_grad():
+        logits, _, _ = model.hip().forward(x, training=True, need_grad=False)
+    sd64 = {k: v.double().requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+            for k, v in sd0.items() if k.startswith(('offset_feats', 'offsets', 'deform_conv'))}
+    want = O.heatmaps(O.aggregate(logits.double().cpu(), sd64, training=True), 1.7)
+    (want * R.double()).sum().backward()
+    err = (heat.detach().double().cpu() - want.detach()).abs().max().item() / want.abs().max().item()
+    assert err <= 1e-3, err
+    dots, errs = [0.0, 0.0, 0.0], []
+    for k, p in head.items():
+        ref = sd64[k].grad
+        got = p.grad.double().cpu()
+        assert got.shape == ref.shape, k
+        if k.startswith('deform_conv') and k.endswith('.bias'):
+            # a per-map constant in front of the spatial softmax has an exactly zero gradient (shift invariance): the
+            # oracle's float64 value is 3e-17, the device's a cancelled f32 sum of 5120 terms of ~1e-4
+            assert got.abs().max().item() <= 1e-6 and ref.abs().max().item() <= 1e-12, k
+            continue
+        dots[0] += float((got * ref).sum()); dots[1] += float((got * got).sum()); dots[2] += float((ref * ref).sum())
+        if ref.norm().item() > 0:
+            errs.append(((got - ref).norm() / ref.norm()).item())
+    cos = dots[0] / np.sqrt(dots[1] * dots[2])
+    print('PoseAggr training: heat-map error {:.2e}, gradient cosine {:.6f}, per-tensor rel L2 median {:.2e} max {:.2e}'.format(
+        err, cos, float(np.median(errs)), max(errs)))
+    assert cos >= 0.999 and float(np.median(errs)) <= 2e-2
+
+
+def test_wrong_frame_count_is_refused_clearly():
+    model, _, _ = _model('fp32')
     with pytest.raises(ValueError, match='5 frames'):
         model(torch.zeros(4, 3, 64, 64, device='cuda'))
