@@ -1,5 +1,6 @@
 """pose_hrnet_PoseAggr — the reference's temporal pose aggregation ("PoseWarper") variant on the HIP path
-(reference lib/models/pose_hrnet_PoseAggr.py), INFERENCE (`USE_WARPING_TEST`).
+(reference lib/models/pose_hrnet_PoseAggr.py): inference (`USE_WARPING_TEST`) and training of the
+aggregation head (`USE_WARPING_TRAIN`).
 
 Input: 5·B frames ordered [prev2 | prev1 | current | next1 | next2] (reference :593-611). The backbone + head of
 pose_hrnet_softmax produce the per-frame heat-map logits; then (reference :612-646)
