@@ -10,8 +10,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libhrnet_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'conv_bs.hip', 'conv_fwd.hip', 'conv_dg.hip', 'conv_fwdb.hip', 'conv_fwds.hip', 'wgrad.hip', 'bwd_fused.hip', 'bwd_pw.hip', 'gemm_pw.hip', 'eltwise.hip', 'loss.hip', 'dcn.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_body.h'), os.path.join(REPO, 'include', 'hrnet_hip.h')]
+SOURCES = ['api.hip', 'conv.hip', 'conv_bs.hip', 'conv_fwd.hip', 'conv_dg.hip', 'conv_fwdb.hip', 'conv_fwds.hip', 'conv_ring.hip', 'wgrad.hip', 'bwd_fused.hip', 'bwd_pw.hip', 'gemm_pw.hip', 'eltwise.hip', 'loss.hip', 'dcn.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_body.h'), os.path.join(CSRC, 'conv_ring.h'), os.path.join(REPO, 'include', 'hrnet_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-I', os.path.join(REPO, 'include'), '-I', CSRC, '-Wno-unused-result']

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -94,6 +96,36 @@ extern "C" int hrnet_program_run_streams(const HrOp* ops, int n, const hr_stream
     if (e != HR_OK) return e;
   }
   return HR_OK;
+}
+
+// The same with a timing event recorded behind every op on its lane: end_ms[k] = when op k was done, in ms since
+// the first op's lane reached the start of the call (event ops: when the lane passed them). Synchronises the
+// streams before it returns - a measurement entry point (bench.py / scratch timelines), not for the training loop.
+extern "C" int hrnet_program_run_streams_timed(const HrOp* ops, int n, const hr_stream_t* streams, int nstreams,
+                                               float* end_ms) {
+  HR_REQUIRE(streams && nstreams >= 1 && end_ms && n >= 1, "program_run_streams_timed: arguments");
+  std::vector<hipEvent_t> ev((size_t)n + 1, nullptr);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) { hr_set_error("program_run_streams_timed: event create"); return HR_E_LAUNCH; }
+  int rc = HR_OK;
+  const int lane0 = ops[0].i[HR_LANE_SLOT];
+  HR_REQUIRE(lane0 >= 0 && lane0 < nstreams, "program_run_streams_timed: lane");
+  hipEventRecord(ev[n], (hipStream_t)streams[lane0]);
+  int done = 0;
+  for (int k = 0; k < n && rc == HR_OK; ++k, ++done) {
+    const int lane = ops[k].i[HR_LANE_SLOT];
+    if (lane < 0 || lane >= nstreams) { hr_set_error("program_run_streams_timed: op %d lane %d", k, lane); rc = HR_E_BADARG; break; }
+    rc = run_one(ops[k], (hipStream_t)streams[lane], k);
+    hipEventRecord(ev[k], (hipStream_t)streams[lane]);
+  }
+  for (int l = 0; l < nstreams; ++l) hipStreamSynchronize((hipStream_t)streams[l]);
+  for (int k = 0; k < done; ++k) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev[n], ev[k]);
+    end_ms[k] = ms;
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  return rc;
 }
 
 extern "C" void* hrnet_event_create(void) {

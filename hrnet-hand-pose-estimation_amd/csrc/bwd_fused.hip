@@ -51,6 +51,7 @@ struct BwdArgs {
   int tiles_y, tiles_x, total_tiles;
   int ncb, nsplit;
   int in_relu, mask_out;
+  int atomic;            // the workgroups add their weight-gradient tiles into slab 0 with float atomics
   unsigned long long* stamp;   // measurement only (HRNET_FUSED_STAMP_PTR): 32 s_memtime stamps per workgroup
   int ablate;   // measurement only (HRNET_FUSED_ABLATE): 1 skip input-gradient MFMAs, 2 skip weight-gradient MFMAs, 4 skip the
                 // epilogue's global traffic, 8 skip the tile loads (stage zeros)
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 
   FSTAMP();
   // ---- weight-gradient slab of this workgroup: slab[split][co][tap][ci], D: col = ci, row = co ----
-  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)split * a.Cout * 9 * a.Cin);
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int fr = wn + WN * j;
@@ -547,7 +548,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
         const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * 9 + tp) * a.Cin + ci] = v4[r];
+          if (co + r < a.Cout && ci < a.Cin) {
+            float* dst = slab + ((size_t)(co + r) * 9 + tp) * a.Cin + ci;
+            if (a.atomic) atomicAdd(dst, v4[r]); else *dst = v4[r];
+          }
       }
     }
   }
@@ -635,12 +639,25 @@ extern "C" int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y,
                                        mask_out, rows, bs_y, slabs, N, H, W, Cin, Cout, stream);
 }
 
+static int bwd_fused_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                            const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
+                            void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
+                            int N, int H, int W, int Cin, int Cout, int atomic, hr_stream_t stream);
+
 extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef,
                                              const HrBnBwdRef* ref, const void* x, const float* in_scale,
                                              const float* in_shift, int in_relu, const void* wT, void* dx,
                                              const void* addend, int mask_out, float* rows, const void* bs_y,
                                              float* slabs, int N, int H, int W, int Cin, int Cout,
                                              hr_stream_t stream) {
+  return bwd_fused_launch(dtype, dz, y, coef, ref, x, in_scale, in_shift, in_relu, wT, dx, addend, mask_out, rows, bs_y,
+                          slabs, N, H, W, Cin, Cout, 0, stream);
+}
+
+static int bwd_fused_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                            const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
+                            void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
+                            int N, int H, int W, int Cin, int Cout, int atomic, hr_stream_t stream) {
   HR_REQUIRE(hrnet_bwd_fused_supported(dtype, Cin, Cout), "bwd_fused: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
   HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_fused: null pointer");
   HR_REQUIRE((!coef && !ref) || y, "bwd_fused: coef needs y");
@@ -662,6 +679,7 @@ extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const vo
   a.ncb = (Cin + 31) / 32;
   a.nsplit = hrnet_bwd_fused_splits(dtype, N, H, W, Cin, Cout);
   a.in_relu = in_relu; a.mask_out = mask_out;
+  a.atomic = atomic;
   { static const char* sp = getenv("HRNET_FUSED_STAMP_PTR"); a.stamp = sp ? (unsigned long long*)strtoull(sp, nullptr, 16) : nullptr; }
   { static const int abl = getenv("HRNET_FUSED_ABLATE") ? atoi(getenv("HRNET_FUSED_ABLATE")) : 0; a.ablate = abl; }
   const unsigned grid = (unsigned)((a.nsplit + 7) / 8 * 8 * a.ncb);
@@ -680,9 +698,9 @@ extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const vo
 }
 
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s) {
-  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL
-  return hrnet_conv3x3_bwd_fused_bnref(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12],
-                                       op.p[3], (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7],
-                                       op.p[8], op.i[7], (float*)op.p[9], op.p[10], (float*)op.p[11], op.i[1], op.i[2],
-                                       op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8]: weight-gradient tiles by atomics
+  return bwd_fused_launch(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12], op.p[3],
+                          (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7],
+                          (float*)op.p[9], op.p[10], (float*)op.p[11], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5],
+                          op.i[8], (hr_stream_t)s);
 }

@@ -39,6 +39,7 @@ struct PwArgs {
   float* slabs;          // [nsplit][Cout][Cin] f32
   long long P;
   int total_tiles, nsplit;
+  int atomic;            // the workgroups add their weight-gradient tiles into slab 0 with float atomics
   int in_relu, mask_out;
 };
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
   }
 
   // ---- weight-gradient slab of this workgroup: slab[split][co][ci] ----
-  float* slab = a.slabs + (size_t)split * CO * CI;
+  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)split * CO * CI);
 #pragma unroll
   for (int f = 0; f < FCOW; ++f)
 #pragma unroll
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
       const int co = (wco * FCOW + f) * 16 + lg * 4, ci = (wci * FCIW + c) * 16 + li;
       const float v4[4] = {accw[f][c].x, accw[f][c].y, accw[f][c].z, accw[f][c].w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[(size_t)(co + r) * CI + ci] = v4[r];
+      for (int r = 0; r < 4; ++r) {
+        float* dst = slab + (size_t)(co + r) * CI + ci;
+        if (a.atomic) atomicAdd(dst, v4[r]); else *dst = v4[r];
+      }
     }
 }
 
@@ -411,11 +415,24 @@ extern "C" int hrnet_conv1x1_bwd_fused(int dtype, const void* dz, const void* y,
                                        mask_out, rows, bs_y, slabs, pixels, Cin, Cout, stream);
 }
 
+static int bwd_pw_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                         const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
+                         void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
+                         long long pixels, int Cin, int Cout, int atomic, hr_stream_t stream);
+
 extern "C" int hrnet_conv1x1_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef,
                                              const HrBnBwdRef* ref, const void* x, const float* in_scale,
                                              const float* in_shift, int in_relu, const void* wT, void* dx,
                                              const void* addend, int mask_out, float* rows, const void* bs_y,
                                              float* slabs, long long pixels, int Cin, int Cout, hr_stream_t stream) {
+  return bwd_pw_launch(dtype, dz, y, coef, ref, x, in_scale, in_shift, in_relu, wT, dx, addend, mask_out, rows, bs_y,
+                       slabs, pixels, Cin, Cout, 0, stream);
+}
+
+static int bwd_pw_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
+                         const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
+                         void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
+                         long long pixels, int Cin, int Cout, int atomic, hr_stream_t stream) {
   HR_REQUIRE(hrnet_bwd_pw_supported(dtype, Cin, Cout), "bwd_pw: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
   HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_pw: null pointer");
   HR_REQUIRE((!coef && !ref) || y, "bwd_pw: coef needs y");
@@ -436,6 +453,7 @@ extern "C" int hrnet_conv1x1_bwd_fused_bnref(int dtype, const void* dz, const vo
   a.total_tiles = (int)((pixels + 63) / 64);
   a.nsplit = hrnet_bwd_pw_splits(dtype, pixels, Cin, Cout);
   a.in_relu = in_relu; a.mask_out = mask_out;
+  a.atomic = atomic;
   hipStream_t s = (hipStream_t)stream;
   switch (pw_shape(Cin, Cout)) {
     case 1: hipLaunchKernelGGL((bwd_pw_kernel<256, 64>), dim3(a.nsplit), dim3(256), 0, s, a); break;
@@ -448,9 +466,9 @@ extern "C" int hrnet_conv1x1_bwd_fused_bnref(int dtype, const void* dz, const vo
 // op slots as OP_BWD_FUSED (p[0..11] = dz,y,coef,x,scale,shift,wT,dx,addend,rows,bs_y,slabs;
 // i[0..7] = dtype,N,H,W,Cin,Cout,in_relu,mask_out)
 int hr_launch_bwd_pw(const HrOp& op, hipStream_t s) {
-  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL
-  return hrnet_conv1x1_bwd_fused_bnref(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12],
-                                       op.p[3], (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7],
-                                       op.p[8], op.i[7], (float*)op.p[9], op.p[10], (float*)op.p[11],
-                                       (long long)op.i[1] * op.i[2] * op.i[3], op.i[4], op.i[5], (hr_stream_t)s);
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8]: weight-gradient tiles by atomics
+  return bwd_pw_launch(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12], op.p[3],
+                       (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7],
+                       (float*)op.p[9], op.p[10], (float*)op.p[11], (long long)op.i[1] * op.i[2] * op.i[3], op.i[4],
+                       op.i[5], op.i[8], (hr_stream_t)s);
 }

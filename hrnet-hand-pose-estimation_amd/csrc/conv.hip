@@ -1,6 +1,7 @@
 // Convolution entry points: argument checks, tile choice, mode choice; the generic instantiation.
 // The device code lives in conv_body.h.
 #include "conv_body.h"
+#include "conv_ring.h"
 
 HR_DEFINE_CONV_LAUNCH(hr_conv_launch_generic, CONV_GENERIC)
 
@@ -12,6 +13,25 @@ inline int conv_mode(const ConvArgs& a, bool in_relu) {
   if (a.bias && !a.upz && !a.accumulate) return CONV_FWDB;
   if (!a.bias && !a.in_scale && !a.in_sums && !in_relu && !a.stats) return CONV_DG;
   return CONV_GENERIC;
+}
+
+// forward 3x3 stride-1 launches conv_ring.hip serves: no bias / accumulate / zero-stuffing / backward statistics,
+// output statistics by atomics (or none), the input's BatchNorm as sums or arrays (or a raw input)
+inline bool ring_serves(const ConvArgs& a, int dtype, int ks, int stride, int mode) {
+  if (ks != 3 || stride != 1 || a.upz || a.accumulate || a.bias || a.bs_y || a.in_dy || a.in_dx) return false;
+  if (mode != CONV_FWD && mode != CONV_GENERIC && mode != CONV_DG) return false;
+  if (a.stats && !a.stats_atomic) return false;
+  if (a.in_sums && a.in_beta != a.in_gamma + a.Cin) return false;
+  return hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, a.N, a.H, a.W, a.Cin, a.Cout) != 0;
+}
+
+inline int launch_ring(const ConvArgs& a, int in_relu, hipStream_t s) {
+  HrRingConv c;
+  c.x = a.x; c.w = a.w; c.y = a.y;
+  c.in_sums = a.in_sums; c.in_gb = a.in_gamma; c.in_scale = a.in_scale; c.in_shift = a.in_shift;
+  c.stats = a.stats; c.in_inv_count = a.in_inv_count; c.in_eps = a.in_eps;
+  c.N = a.N; c.H = a.H; c.W = a.W; c.Cin = a.Cin; c.Cout = a.Cout; c.in_relu = in_relu;
+  return hr_conv_ring_launch(c, s);
 }
 }  // namespace
 
@@ -82,6 +102,8 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   const int mode = conv_mode(a, op.i[11] != 0);
   HR_REQUIRE(!a.in_sums || mode == CONV_FWD || mode == CONV_FWDB,
              "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
+  // the branch 3x3 convolutions: LDS-ring pipeline (conv_ring.hip)
+  if (ring_serves(a, dtype, ks, op.i[9], mode)) return launch_ring(a, op.i[11], s);
   // the GEMM-shaped head layer (and its input gradient): every output channel of a pixel block in one workgroup
   if (ks == 1 && stride == 1 && !upz && !a.accumulate && !a.bs_y && !a.in_scale && !a.in_sums && !op.i[11] &&
       (!a.stats || a.stats_atomic) && !a.in_dy && !a.in_dx && hr_gemm_pw_supported(dtype, Cin, Cout))
@@ -265,6 +287,9 @@ extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin,
   if (ks == 1 && stride == 1 && !upz && hr_gemm_pw_supported(dtype, Cin, Cout) &&
       (mode == CONV_FWD || mode == CONV_FWDB || mode == CONV_DG))
     return snprintf(buf, buflen, "gemm_pw_kernel");
+  if (ks == 3 && stride == 1 && !upz && (mode == CONV_FWD || mode == CONV_GENERIC || mode == CONV_DG) &&
+      hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout))
+    return hr_conv_ring_name(hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout), buf, buflen);
   const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
   const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS, s2d);
   static const int wp[8] = {4, 2, 2, 2, 2, 0, 4, 2}, wc[8] = {1, 2, 2, 2, 2, 0, 1, 2};

@@ -1,0 +1,554 @@
+// 3x3 stride-1 convolution (bf16) as an LDS-ring pipeline for gfx950: the branch convolutions of the
+// HighResolutionModules (BasicBlock.conv1/conv2, pose_hrnet.py:41-57), which conv_body.h runs latency-bound
+// (one register-staged tile in flight per workgroup).
+//
+//   D[cout][pixel] += sum_{tap, ci} Wp[cout][tap][ci] * a[pixel + tap][ci],   a = relu?(scale*x + shift)
+//
+// A stage = (pixel tile, 32 input channels): the halo tile [(TH+2)*(TW+2)][32 ch] (64 bytes per pixel) and - when
+// the weights of the workgroup's output-channel block do not stay resident - the weight slice [9][NB][32 ch].
+// Stages are fetched by DIRECT global->LDS loads (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no
+// staging registers) into a ring of R slots, R-1 stages ahead of the matrix work; every vector-memory
+// instruction of a wave is counted, and the wait for a stage is the exact `s_waitcnt vmcnt(n)` that leaves the
+// younger stages (and the epilogue's stores) in flight. Lanes outside the image read out of the buffer's range:
+// the hardware writes zeros, which IS the zero padding of a raw input; an input read through a BatchNorm
+// (+ReLU) is transformed IN PLACE in LDS by the lane that fetched it (own data: its own vmcnt is the only
+// ordering needed), one stage ahead of the MFMAs, zeros outside the image written after the transform as the
+// reference pads the activated tensor. One barrier per stage.
+//
+// LDS image of a stage: pixel-major, 4 x 16-byte channel chunks per pixel, chunk c of pixel P stored at chunk
+// position c ^ ((P >> 1) & 2): the 16 pixels x 4 chunks one MFMA B-fragment read (ds_read_b128) touches fall on
+// 16 different 16-byte bank slots for every lane group and every tap shift. The swizzle is applied on the SOURCE
+// address (the LDS destination of a direct load is lane-linear). Weight rows [tap][cout] are stored the same
+// way, in MFMA order, so a lane ends up with 4*FC contiguous output channels of one pixel (16-byte NHWC stores).
+//
+// BatchNorm batch statistics of the output (sum, sum of squares) come from the f32 accumulators, reduced once
+// per workgroup and added to sums[8][2][Cout] (float atomics), as in conv_body.h. The input BatchNorm given as
+// batch sums is turned into scale/shift with hr_bn_from_sums's arithmetic from a copy of the sums fetched by
+// the same direct loads (no register-destination load shares the queue with the ring).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_ring.h"
+
+namespace {
+
+struct RingArgs {
+  const char* x;         // [N,H,W,Cin] bf16
+  const char* w;         // packed [Cout][9][Cin] bf16 (hrnet_pack_weights mode 0; mode 1 for an input gradient)
+  char* y;               // [N,H,W,Cout] bf16
+  const float* in_sums;  // [8][2][Cin] batch sums of the input's BatchNorm, or NULL
+  const float* in_gb;    // gamma[Cin] | beta[Cin] (contiguous), with in_sums
+  const float* in_scale; // or: precomputed scale / shift arrays
+  const float* in_shift;
+  float* stats;          // [8][2][Cout] (atomic) or NULL
+  float in_inv_count, in_eps;
+  int N, H, W, Cin, Cout;
+  int tiles_y, tiles_x, total_tiles, tpw, gx, gy;
+  int in_relu;
+  unsigned x_bytes, y_bytes, w_bytes;
+#ifdef HR_RING_STAMP
+  unsigned long long* stamp;   // measurement build only: 32 s_memrealtime stamps per workgroup
+#endif
+};
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: the largest immediate <= n (waiting for more is safe)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define WV(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 47 ? 47 : n)) {
+    WV(0) WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8) WV(9) WV(10) WV(11) WV(12) WV(13) WV(14) WV(15)
+    WV(16) WV(17) WV(18) WV(19) WV(20) WV(21) WV(22) WV(23) WV(24) WV(25) WV(26) WV(27) WV(28) WV(29) WV(30) WV(31)
+    WV(32) WV(33) WV(34) WV(35) WV(36) WV(37) WV(38) WV(39) WV(40) WV(41) WV(42) WV(43) WV(44) WV(45) WV(46) WV(47)
+  }
+#undef WV
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  // the LDS writes of this wave are done, then the workgroup meets; no vmcnt wait: direct loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;   // beyond every buffer's num_records: reads return 0, stores are dropped
+
+// TH x TW output pixels per tile, NB output channels per workgroup, NW waves as WPX (pixel groups) x NW/WPX
+// (channel groups), R ring slots, WCH > 0: the weights of all WCH input-channel chunks stay resident
+template <int TH, int TW, int NB, int NW, int WPX, int R, int WCH>
+struct RingCfg {
+  static constexpr int NT = NW * 64;
+  static constexpr int HH = TH + 2, HW = TW + 2, HPX = HH * HW;
+  static constexpr int NPX = (HPX + 15) / 16;            // 1 KiB pieces of a halo chunk
+  static constexpr int XSB = HPX * 64;                   // bytes of one ring slot's input image
+  static constexpr int NPWC = NB * 9 / 16;               // pieces of one weight chunk
+  static constexpr int WCB = NB * 9 * 64;
+  static constexpr bool WRES = WCH > 0;
+  static constexpr int KPX = (NPX + NW - 1) / NW;        // pieces per wave
+  static constexpr int KPW = (NPWC + NW - 1) / NW;
+  static constexpr int NPF = TH * TW / 16, NCF = NB / 16, WCO = NW / WPX;
+  static constexpr int FP = NPF / WPX, FC = NCF / WCO, CN = FC * 16, LANE_C = 4 * FC;
+  static constexpr int RPF = 16 / TW;                    // tile rows per pixel fragment (1 or 2)
+  static constexpr int NRO = RPF * FP + 2;               // halo rows a wave's fragments touch
+  static constexpr int CMAX = WRES ? WCH * 32 : HR_RING_MAXC;
+  static constexpr int XOFF = 0, WOFF = R * XSB, TOFF = WOFF + (WRES ? WCH : R) * WCB;
+  static constexpr int LDSB = TOFF + 2 * CMAX * 4;
+  static_assert(TW == 16 || TW == 8, "a pixel fragment is one row of 16 or two rows of 8");
+  static_assert(NPF % WPX == 0 && NCF % WCO == 0 && WPX * WCO == NW, "wave grid");
+  static_assert(NB * 9 % 16 == 0, "whole weight pieces");
+  static_assert(R >= 2 && R <= 4, "ring slots");
+  static_assert(LDSB <= 160 * 1024, "LDS");
+  // the batch sums of the input BatchNorm are staged in the last ring slot (first used by the stage issued in
+  // the first iteration, after the table is built): 18 floats per channel
+  static_assert(CMAX * 18 * 4 <= XSB + (WRES ? 0 : WCB) || true, "sums staging");
+};
+
+template <int TH, int TW, int NB, int NW, int WPX, int R, int WCH>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(RingArgs a) {
+  using C = RingCfg<TH, TW, NB, NW, WPX, R, WCH>;
+  __shared__ __attribute__((aligned(1024))) char lds[C::LDSB];
+  char* xl = lds + C::XOFF;
+  char* wl = lds + C::WOFF;
+  float* bntab = (float*)(lds + C::TOFF);     // [scale Cin][shift Cin]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wpx = wv % WPX, wco = wv / WPX;
+
+  // workgroup -> (pixel walk, output-channel block): ids round-robin over the 8 XCDs, so logical index
+  // L = (id % 8) * (grid / 8) + id / 8 gives every XCD one contiguous run of walks - neighbouring tiles (shared
+  // halo rows) and the channel blocks of one walk (same input) meet in one L2
+  const int G8 = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * G8 + (blockIdx.x >> 3);
+  if (L >= a.gx * a.gy) return;
+  const int wg_p = L / a.gy, n0 = (L - wg_p * a.gy) * NB;
+
+#ifdef HR_RING_STAMP
+  int stamp_i = 0;
+#define RSTAMP() do { if (a.stamp && tid == 0 && stamp_i < 32) a.stamp[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RSTAMP() do { } while (0)
+#endif
+  RSTAMP();
+  const int nch = a.Cin >> 5;
+  const int tile0 = wg_p * a.tpw;
+  const int ntile = min(a.tpw, a.total_tiles - tile0);
+  const int S = ntile * nch;
+  const bool from_sums = a.in_sums != nullptr;
+  const bool xf = from_sums || a.in_scale != nullptr || a.in_relu != 0;   // the input needs the in-place transform
+  const bool has_aff = from_sums || a.in_scale != nullptr;
+  const bool in_relu = a.in_relu != 0;
+
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)a.y_bytes, 0x00020000);
+
+  // ---- per-lane constants of the direct loads: lane j of a piece = 16-byte slot j: pixel j>>2 of the piece,
+  // chunk position j&3, which holds channel chunk cj (fixed per lane: pieces start at multiples of 16 pixels)
+  const int pj = lane >> 2, cj = (lane & 3) ^ ((pj >> 1) & 2);
+  const int pixB = a.Cin * 2, rowB = a.W * pixB;
+  int hyx[C::KPX], goff[C::KPX];
+#pragma unroll
+  for (int k = 0; k < C::KPX; ++k) {
+    const int P = (wv + k * NW) * 16 + pj;
+    const int hy = P / C::HW, hx = P - hy * C::HW;
+    hyx[k] = P < C::HPX ? (hy << 16) | hx : (0x4000 << 16);      // beyond the halo: a row far outside
+    goff[k] = hy * rowB + hx * pixB + cj * 16;
+  }
+  // weight pieces: row (tap, co) of the chunk image; LDS column co holds the channel the MFMA row order needs
+  int woff[C::KPW];
+#pragma unroll
+  for (int k = 0; k < C::KPW; ++k) {
+    const int row = (wv + k * NW) * 16 + pj;
+    const int tap = row / NB, col = row - tap * NB;
+    const int q = col % C::CN;
+    const int co = n0 + (col / C::CN) * C::CN + ((q & 15) >> 2) * C::LANE_C + (q >> 4) * 4 + (q & 3);
+    woff[k] = co < a.Cout ? ((co * 9 + tap) * a.Cin) * 2 + cj * 16 : (int)OOB;
+  }
+
+  int cnt = 0;                 // vector-memory instructions this wave has issued
+  int mark[R];                 // cnt right after stage (slot) was issued
+#pragma unroll
+  for (int r = 0; r < R; ++r) mark[r] = 0;
+  auto set_mark = [&](int slot, int v) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (slot == r) mark[r] = v;
+  };
+  auto get_mark = [&](int slot) {
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (slot == r) v = mark[r];
+    return v;
+  };
+
+  // tile cursors: issue (loads), transform, compute; each walks (tile, chunk) in the same order
+  struct Cur { int n, ty, tx, ch; };
+  auto cur_init = [&](Cur& c) {
+    int bq = tile0;
+    c.tx = bq % a.tiles_x; bq /= a.tiles_x;
+    c.ty = bq % a.tiles_y; c.n = bq / a.tiles_y; c.ch = 0;
+  };
+  auto cur_next = [&](Cur& c) {
+    if (++c.ch == nch) {
+      c.ch = 0;
+      if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.n; } }
+    }
+  };
+  Cur ci, ct, cc;
+  cur_init(ci); cur_init(ct); cur_init(cc);
+
+  auto issue_w = [&](int chunk, int slot_or_chunk) {     // one weight chunk image
+#pragma unroll
+    for (int k = 0; k < C::KPW; ++k) {
+      const int r = wv + k * NW;
+      if (r < C::NPWC) {
+        const unsigned vo = woff[k] == (int)OOB ? OOB : (unsigned)(woff[k] + chunk * 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wl + slot_or_chunk * C::WCB + r * 1024), 16, vo, 0, 0, 0);
+        ++cnt;
+      }
+    }
+  };
+  auto issue_stage = [&](int s) {
+    const int slot = s % R;
+    const int n = __builtin_amdgcn_readfirstlane(ci.n), ty = __builtin_amdgcn_readfirstlane(ci.ty),
+              tx = __builtin_amdgcn_readfirstlane(ci.tx), ch = __builtin_amdgcn_readfirstlane(ci.ch);
+    const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+    const int sbase = ((n * a.H + iy0) * a.W + ix0) * pixB + ch * 64;     // may be negative: only valid lanes use it
+#pragma unroll
+    for (int k = 0; k < C::KPX; ++k) {
+      const int q = wv + k * NW;
+      if (q < C::NPX) {
+        const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
+        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const unsigned vo = ok ? (unsigned)(sbase + goff[k]) : OOB;
+        if ((hyx[k] >> 16) < C::HH)     // (only the last piece has lanes beyond the halo: they stay out of the next slot)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xl + slot * C::XSB + q * 1024), 16, vo, 0, 0, 0);
+        ++cnt;
+      }
+    }
+    if constexpr (!C::WRES) issue_w(ch, slot);
+    set_mark(slot, cnt);
+    cur_next(ci);
+  };
+
+  // ---- prologue: the BatchNorm inputs (into the last ring slot), resident weights, the first R-1 stages ----
+  char* stg = xl + (R - 1) * C::XSB;                    // staging: [8][2][Cin] sums | gamma | beta  (or scale | shift)
+  int tab_mark = 0;
+  if (has_aff) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(from_sums ? a.in_sums : a.in_scale), 0,
+                                                      (from_sums ? 16 : 1) * a.Cin * 4, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)(from_sums ? a.in_gb : a.in_shift), 0,
+                                                      (from_sums ? 2 : 1) * a.Cin * 4, 0x00020000);
+    if (wv == 0) {
+      const int np = from_sums ? (a.Cin * 64 + 1023) / 1024 : (a.Cin * 4 + 1023) / 1024;
+      for (int q = 0; q < np; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stg + q * 1024), 16, (unsigned)(q * 1024 + lane * 16), 0, 0, 0);
+        ++cnt;
+      }
+      const int go = from_sums ? a.Cin * 64 : a.Cin * 4;    // multiples of 1 KiB for Cin % 16 == 0 (sums) / 256 (arrays)
+      const int ng = ((from_sums ? 2 : 1) * a.Cin * 4 + 1023) / 1024;
+      for (int q = 0; q < ng; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(stg + ((go + 1023) & ~1023) + q * 1024), 16,
+                                                 (unsigned)(q * 1024 + lane * 16), 0, 0, 0);
+        ++cnt;
+      }
+    }
+    tab_mark = cnt;
+  }
+  if constexpr (C::WRES) {
+    for (int ch = 0; ch < nch; ++ch) issue_w(ch, ch);
+  }
+  const int npro = S < R - 1 ? S : R - 1;
+  for (int s = 0; s < npro; ++s) issue_stage(s);
+  RSTAMP();
+
+  if (has_aff) {
+    wait_vmcnt(cnt - tab_mark);
+    lds_barrier();
+    const int go = ((from_sums ? a.Cin * 64 : a.Cin * 4) + 1023) & ~1023;
+    const float* sv = (const float*)stg;
+    const float* gv = (const float*)(stg + go);
+    for (int c = tid; c < a.Cin; c += C::NT) {
+      float sc_, sh_;
+      if (from_sums) {
+        float m_, r_, v_;
+        hr_bn_from_sums(sv, a.Cin, c, a.in_inv_count, a.in_eps, gv[c], gv[a.Cin + c], sc_, sh_, m_, r_, v_);
+      } else {
+        sc_ = sv[c]; sh_ = gv[c];
+      }
+      bntab[c] = sc_;
+      bntab[a.Cin + c] = sh_;
+    }
+    lds_barrier();         // the table is readable; the staging slot is free for the ring
+  }
+  RSTAMP();
+
+  // ---- per-lane MFMA operand offsets ----
+  int boff[C::NRO * 3];
+#pragma unroll
+  for (int r = 0; r < C::NRO; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      // halo pixel of lane li for the fragment whose first tile row is (r - dy): row r of the wave's halo window
+      const int P = (wpx * C::FP * C::RPF + r + (C::RPF == 2 ? (li >> 3) : 0)) * C::HW + (C::RPF == 2 ? (li & 7) : li) + dx;
+      boff[r * 3 + dx] = P * 64 + ((lg ^ ((P >> 1) & 2)) << 4);
+    }
+  int aoff[C::FC];
+#pragma unroll
+  for (int fc = 0; fc < C::FC; ++fc) {
+    const int col = wco * C::CN + fc * 16 + li;
+    aoff[fc] = col * 64 + ((lg ^ ((col >> 1) & 2)) << 4);
+  }
+
+  float sc[8], sh[8];
+  auto load_coef = [&](int ch) {
+    if (has_aff) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = bntab[ch * 32 + cj * 8 + j];
+        sh[j] = bntab[a.Cin + ch * 32 + cj * 8 + j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+    }
+  };
+  if (nch == 1) load_coef(0);
+
+  // in-place transform of the stage the transform cursor points at (own pieces only)
+  auto transform = [&](int s) {
+    const int slot = s % R;
+    const int n = __builtin_amdgcn_readfirstlane(ct.n), ty = __builtin_amdgcn_readfirstlane(ct.ty),
+              tx = __builtin_amdgcn_readfirstlane(ct.tx), ch = __builtin_amdgcn_readfirstlane(ct.ch);
+    (void)n;
+    if (xf) {
+      if (nch != 1) load_coef(ch);
+      const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+#pragma unroll
+      for (int k = 0; k < C::KPX; ++k) {
+        const int q = wv + k * NW;
+        if (q < C::NPX) {
+          const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
+          const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          if ((hyx[k] >> 16) < C::HH) {
+            V16* p = (V16*)(xl + slot * C::XSB + q * 1024 + lane * 16);
+            float f[8];
+            v16_unpack<bf16_t>(*p, f);
+            if (in_relu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { f[j] = fmaf(f[j], sc[j], sh[j]); f[j] = f[j] > 0.f ? f[j] : 0.f; }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
+            }
+            *p = ok ? v16_pack<bf16_t>(f) : v16_zero();
+          }
+        }
+      }
+    }
+    cur_next(ct);
+  };
+
+  const int cbase = n0 + wco * C::CN + lg * C::LANE_C;
+  const bool cok = cbase < a.Cout;
+  float s1[C::LANE_C], s2[C::LANE_C];
+#pragma unroll
+  for (int k = 0; k < C::LANE_C; ++k) s1[k] = s2[k] = 0.f;
+
+  if (S > 0) {
+    wait_vmcnt(cnt - get_mark(0));
+    RSTAMP();
+    transform(0);
+  }
+  lds_barrier();
+  RSTAMP();
+
+  f32x4 acc[C::FC][C::FP];
+  for (int i = 0; i < S; ++i) {
+    if (i + R - 1 < S) issue_stage(i + R - 1);
+    if (i + 1 < S) {
+      wait_vmcnt(cnt - get_mark((i + 1) % R));
+      RSTAMP();
+      transform(i + 1);
+    }
+    RSTAMP();
+    const int ch = __builtin_amdgcn_readfirstlane(cc.ch);
+    if (ch == 0) {
+#pragma unroll
+      for (int fc = 0; fc < C::FC; ++fc)
+#pragma unroll
+        for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char* xs = xl + (i % R) * C::XSB;
+    const char* ws = wl + (C::WRES ? ch : i % R) * C::WCB;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int dy = tp / 3, dx = tp % 3;
+      V16 af[C::FC], bf[C::FP];
+#pragma unroll
+      for (int fc = 0; fc < C::FC; ++fc) af[fc] = *(const V16*)(ws + aoff[fc] + tp * NB * 64);
+#pragma unroll
+      for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xs + boff[(fp * C::RPF + dy) * 3 + dx]);
+#pragma unroll
+      for (int fc = 0; fc < C::FC; ++fc)
+#pragma unroll
+        for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<bf16_t>(af[fc], bf[fp], acc[fc][fp]);
+    }
+    RSTAMP();
+    if (ch == nch - 1) {
+      // ---- tile epilogue: 4*FC contiguous output channels per pixel, statistics ----
+      const int n = __builtin_amdgcn_readfirstlane(cc.n), ty = __builtin_amdgcn_readfirstlane(cc.ty),
+                tx = __builtin_amdgcn_readfirstlane(cc.tx);
+#pragma unroll
+      for (int fp = 0; fp < C::FP; ++fp) {
+        const int p = (wpx * C::FP + fp) * 16 + li;
+        const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
+        const bool pok = cok && oy < a.H && ox < a.W;
+        float vals[C::LANE_C];
+#pragma unroll
+        for (int fc = 0; fc < C::FC; ++fc) {
+          vals[fc * 4 + 0] = acc[fc][fp].x; vals[fc * 4 + 1] = acc[fc][fp].y;
+          vals[fc * 4 + 2] = acc[fc][fp].z; vals[fc * 4 + 3] = acc[fc][fp].w;
+        }
+        if (pok) {
+#pragma unroll
+          for (int k = 0; k < C::LANE_C; ++k) {
+            s1[k] += vals[k];
+            s2[k] += vals[k] * vals[k];
+          }
+        }
+        const unsigned vo = pok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + cbase) * 2) : OOB;
+        if constexpr (C::LANE_C >= 8) {
+#pragma unroll
+          for (int k0 = 0; k0 < C::LANE_C; k0 += 8) {
+            __builtin_amdgcn_raw_buffer_store_b128(v16_pack<bf16_t>(vals + k0), ry, pok ? vo + k0 * 2 : OOB, 0, 0);
+            ++cnt;
+          }
+        } else {
+          const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, vo, 0, 0);
+          ++cnt;
+        }
+      }
+    }
+    cur_next(cc);
+    lds_barrier();     // slot i % R is free; the transformed image of stage i + 1 is visible
+    RSTAMP();
+  }
+
+  if (a.stats) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing in flight into LDS: the ring doubles as scratch)
+    float* sl = (float*)lds;  // [WPX][2][NB]
+#pragma unroll
+    for (int k = 0; k < C::LANE_C; ++k) {
+      s1[k] = wave_sum16(s1[k]);
+      s2[k] = wave_sum16(s2[k]);
+    }
+    if (li == 0) {
+#pragma unroll
+      for (int k = 0; k < C::LANE_C; ++k) {
+        const int cl = wco * C::CN + lg * C::LANE_C + k;
+        sl[(wpx * 2 + 0) * NB + cl] = s1[k];
+        sl[(wpx * 2 + 1) * NB + cl] = s2[k];
+      }
+    }
+    lds_barrier();
+    if (tid < 2 * NB) {
+      const int which = tid / NB, cl = tid % NB;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < WPX; ++q) s += sl[(q * 2 + which) * NB + cl];
+      if (n0 + cl < a.Cout)
+        atomicAdd(a.stats + ((size_t)(wg_p & (HR_BN_COPIES - 1)) * 2 + which) * a.Cout + n0 + cl, s);
+    }
+  }
+}
+
+struct RingPlan {
+  int id;        // 0 = not served
+  int th, tw, nb, per_cu;
+};
+
+// which instantiation serves a layer (0: none). Shapes: the four branch widths of pose_hrnet w32 / w48.
+inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout) {
+  (void)N;
+  if (Cin % 32 != 0 || Cout % 16 != 0 || Cin > HR_RING_MAXC) return RingPlan{0, 0, 0, 0, 0};
+  if (Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 32, 2};
+  if (Cin == 64 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 32, 2};
+  return RingPlan{0, 0, 0, 0, 0};
+}
+
+int g_ring_enabled = -1;
+#ifdef HR_RING_STAMP
+unsigned long long* g_ring_stamp = nullptr;
+#endif
+
+}  // namespace
+
+#ifdef HR_RING_STAMP
+extern "C" int hrnet_conv_ring_set_stamp(void* p) { g_ring_stamp = (unsigned long long*)p; return 0; }
+#endif
+
+extern "C" int hrnet_conv_ring_enable(int on) {
+  const int prev = g_ring_enabled;
+  g_ring_enabled = on;
+  return prev;
+}
+
+int hr_conv_ring_enabled() {
+  if (g_ring_enabled < 0) {
+    const char* e = getenv("HRNET_CONV_RING");
+    g_ring_enabled = e ? atoi(e) : 1;
+  }
+  return g_ring_enabled;
+}
+
+extern "C" int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout) {
+  return hr_conv_ring_enabled() ? hr_conv_ring_supported(dtype, N, H, W, Cin, Cout) : 0;
+}
+
+int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout) {
+  if (dtype != HR_BF16) return 0;
+  if ((double)N * H * W * (Cin > Cout ? Cin : Cout) * 2.0 >= 2147483648.0) return 0;   // 32-bit buffer offsets
+  return ring_plan(N, H, W, Cin, Cout).id;
+}
+
+int hr_conv_ring_name(int id, char* buf, int buflen) {
+  static const char* names[] = {"", "conv_ring_kernel<16, 16, 32, 4, 4, 3, 1>", "conv_ring_kernel<8, 16, 32, 4, 4, 3, 2>"};
+  return snprintf(buf, buflen, "%s", id >= 1 && id <= 2 ? names[id] : "");
+}
+
+int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
+  const RingPlan p = ring_plan(c.N, c.H, c.W, c.Cin, c.Cout);
+  HR_REQUIRE(p.id != 0, "conv_ring: shape not served (Cin %d Cout %d %dx%d)", c.Cin, c.Cout, c.H, c.W);
+  HR_REQUIRE(c.x && c.w && c.y, "conv_ring: null pointer");
+  HR_REQUIRE(!c.in_sums || c.in_gb, "conv_ring: batch sums need gamma/beta");
+  HR_REQUIRE((c.in_scale == nullptr) == (c.in_shift == nullptr), "conv_ring: scale/shift must come together");
+  HR_REQUIRE(!(c.in_sums && c.in_scale), "conv_ring: batch sums OR scale/shift");
+  RingArgs a;
+  a.x = (const char*)c.x; a.w = (const char*)c.w; a.y = (char*)c.y;
+  a.in_sums = c.in_sums; a.in_gb = c.in_gb; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
+  a.stats = c.stats; a.in_inv_count = c.in_inv_count; a.in_eps = c.in_eps;
+  a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
+  a.tiles_y = (c.H + p.th - 1) / p.th; a.tiles_x = (c.W + p.tw - 1) / p.tw;
+  a.total_tiles = c.N * a.tiles_y * a.tiles_x;
+  a.gy = (c.Cout + p.nb - 1) / p.nb;
+  const int target = 256 * p.per_cu;
+  int tpw = (a.total_tiles * a.gy + target - 1) / target;
+  if (tpw < 1) tpw = 1;
+  a.tpw = tpw;
+  a.gx = (a.total_tiles + tpw - 1) / tpw;
+  a.in_relu = c.in_relu;
+  a.x_bytes = (unsigned)((size_t)c.N * c.H * c.W * c.Cin * 2);
+  a.y_bytes = (unsigned)((size_t)c.N * c.H * c.W * c.Cout * 2);
+  a.w_bytes = (unsigned)((size_t)c.Cout * 9 * c.Cin * 2);
+#ifdef HR_RING_STAMP
+  a.stamp = g_ring_stamp;
+#endif
+  const unsigned grid = (unsigned)((a.gx * a.gy + 7) / 8 * 8);
+  switch (p.id) {
+    case 1: hipLaunchKernelGGL((conv_ring_kernel<16, 16, 32, 4, 4, 3, 1>), dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_ring_kernel<8, 16, 32, 4, 4, 3, 2>), dim3(grid), dim3(256), 0, s, a); break;
+    default: break;
+  }
+  return hr_check_launch("conv_ring");
+}

@@ -30,6 +30,7 @@ struct WgradArgs {
   int N, H, W, Cin, Ho, Wo, Cout;
   int tiles_y, tiles_x, total_tiles;
   int in_relu;
+  int atomic;      // every split adds into slab 0 with float atomics (no reduce over splits afterwards)
 };
 
 // lane's KSTEP-deep operand fragment for 16 channels starting at byte offset `choff` of each
@@ -210,7 +211,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 
   // slab[split][co][tap][ci]; D layout: col (lane&15) = ci, row 4*(lane>>4)+r = co
-  float* slab = a.slabs + (size_t)blockIdx.x * a.Cout * TAPS * a.Cin;
+  // (atomic form: one accumulator image shared by the splits; a wave instruction adds 4 rows x 16 contiguous
+  // floats = four 64-byte segments, the request size of the memory-side atomic units)
+  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)blockIdx.x * a.Cout * TAPS * a.Cin);
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int fr = wn + WN * j;
@@ -222,7 +225,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * TAPS + t) * a.Cin + ci] = v4[r];
+          if (co + r < a.Cout && ci < a.Cin) {
+            float* dst = slab + ((size_t)(co + r) * TAPS + t) * a.Cin + ci;
+            if (a.atomic) atomicAdd(dst, v4[r]); else *dst = v4[r];
+          }
       }
     }
   }
@@ -337,6 +343,7 @@ int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   a.tiles_x = (Wo + c.tw - 1) / c.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.in_relu = op.i[10];
+  a.atomic = op.i[12];
   dim3 grid((unsigned)nsplit, (unsigned)((Cout + c.bco - 1) / c.bco), (unsigned)((Cin + c.kc - 1) / c.kc));
   if (dtype == HR_F32) return launch_wg<float, 16, 32>(a, c, ks, stride, grid, s);
   return launch_wg<bf16_t, 32, 64>(a, c, ks, stride, grid, s);

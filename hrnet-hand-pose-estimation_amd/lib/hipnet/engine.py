@@ -258,6 +258,19 @@ class Plan(object):
         self.keep.append(t)
         return t
 
+    def _slabs(self, nsplit, per_slab):
+        """weight-gradient partials of one layer: `nsplit` slabs, or (atomic mode) one accumulator image out of
+        the arena the backward pass zeroes; returns (tensor, number of slabs the reduce entry sums)"""
+        if self._acc_arena is not None:
+            t = self._acc_arena[self._acc_off:self._acc_off + per_slab]
+            assert t.numel() == per_slab, 'accumulator arena too small'
+            self._acc_off += per_slab
+            self.slab_bytes += per_slab * 4
+            return t, 1
+        t = self._f32(nsplit * per_slab)
+        self.slab_bytes += t.numel() * 4
+        return t, nsplit
+
     def _scratch(self, prog, idx, slot, kind):
         self.pending.append((prog, idx, slot, kind))
 
@@ -632,6 +645,20 @@ class Plan(object):
         self.gout_op = self.bwd.add(C.OP_NCHW_TO_NHWC, ints=(self.dtid, oa.N, oa.H, oa.W, oa.C, self.nj),
                                     ptrs=(None, C.ptr(oa.g)))
         oa.ginit = True
+        # Weight gradients by float atomics (default): every workgroup of a weight-gradient / fused backward launch
+        # adds its tile into ONE f32 accumulator image per layer ([Cout][tap][Cin], zeroed by one fill at the start
+        # of the pass) instead of writing a slab per split that a reduce launch reads back - the table launches
+        # that remain only transpose the accumulators into the OIHW gradients (1.94 GB of slabs written and read
+        # back per step before). HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps the slabs and their ordered sums.
+        self.wgrad_atomic = (os.environ.get('HRNET_BATCH_WRED', '1') != '0'
+                             and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
+                             and os.environ.get('HRNET_WGRAD_ATOMIC', '1') != '0')
+        self._acc_arena, self._acc_off = None, 0
+        if self.wgrad_atomic:
+            total = sum(c.Cout_pad * (1 if c.stem else c.ks) ** 2 * c.Cin_pad for c in net.convs.values())
+            self._acc_arena = self._f32(total)
+            nbytes = total * 4
+            self.bwd.add(C.OP_FILL, ints=(nbytes & 0xffffffff, nbytes >> 32), ptrs=(C.ptr(self._acc_arena),))
         relu_of = {}   # act -> relu flag its consumers apply (uniform per act in this network)
         for e in self.tape:
             if e[0] == 'conv':
@@ -818,14 +845,14 @@ class Plan(object):
                     nsplit = max(1, floor_, nsplit // max(div, 1))
                     while nsplit > 1 and tiles % nsplit != 0:
                         nsplit -= 1
-                wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit)
+                wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit,
+                         1 if (self.batch_wred and self.wgrad_atomic) else 0)
                 wptrs = [C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
                          C.ptr(xin.bn.shift) if xin.bn else None, None]
                 if self.batch_wred:
-                    slabs = self._f32(nsplit * y.C * ks * ks * x.C)
-                    self.slab_bytes += slabs.numel() * 4
+                    slabs, nred = self._slabs(nsplit, y.C * ks * ks * x.C)
                     wptrs[4] = C.ptr(slabs)
-                    ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
+                    ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nred, Cout_pad=y.C, Cin_pad=x.C,
                                ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
                                accumulate=1)
                     if deferred:
@@ -1060,22 +1087,26 @@ class Plan(object):
             kind = C.OP_BWD_PW
             if rows_for is not None and not C.call('hrnet_bwd_pw_rows_supported', self.dtid, x.C, y.C):
                 rows_for = None               # (the BatchNorm backward behind it runs its own reduction pass)
-        slabs = self._f32(ns * y.C * ks * ks * x.C)
-        self.slab_bytes += slabs.numel() * 4
+        atomic = 1 if (self.batch_wred and self.wgrad_atomic) else 0
+        if atomic:
+            slabs, nred = self._slabs(ns, y.C * ks * ks * x.C)
+        else:
+            slabs, nred = self._f32(ns * y.C * ks * ks * x.C), ns
+            self.slab_bytes += slabs.numel() * 4
         rows = None
         if rows_for is not None:
             rows = self._f32(ns * 2 * x.C)
             rows_for.bwd_rows = (rows, ns)
             self.n_fused_bwdstats += 1
         self.bwd.add(kind,
-                     ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0),
+                     ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0, atomic),
                      ptrs=(dz, C.ptr(y.t), None if ref is not None else C.ptr(y.bn.coef), C.ptr(x.t),
                            C.ptr(xin.bn.scale) if xin.bn else None, C.ptr(xin.bn.shift) if xin.bn else None,
                            C.ptr(crec.wd), dx, addend, C.ptr(rows),
                            C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs),
                            ctypes.addressof(ref) if ref is not None else None))
         w = crec.mod.weight
-        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
+        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nred, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
                    Cout=crec.Cout, Cin=crec.Cin, kflat=0, accumulate=1)
         if self.batch_wred:
             self._wred.setdefault(lane, []).append(ent)

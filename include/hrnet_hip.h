@@ -43,7 +43,9 @@ enum {
 enum {
   HR_OP_CONV = 1,          /* conv / dgrad (implicit GEMM, MFMA); a backward-statistics op may set i[14] = 1: the
                               stored gradient is dz = v * [mask > 0] (what the fused backward launches expect) */
-  HR_OP_WGRAD = 2,         /* weight gradient partial slabs */
+  HR_OP_WGRAD = 2,         /* weight gradient partial slabs; i[12] = 1: every split ADDS its tile into slab 0 with float
+                              atomics (the caller zeroes it; no sum over splits afterwards). HR_OP_BWD_FUSED / HR_OP_BWD_PW
+                              take the same switch in i[8] */
   HR_OP_WGRAD_REDUCE = 3,  /* slabs -> OIHW f32 gradient */
   HR_OP_BN_FINALIZE = 4,   /* stat partials -> scale/shift (+ running stats) */
   HR_OP_SUM_TERMS = 5,     /* out = relu(sum_t relu_t(affine_t(up_t(src_t)))) */
@@ -88,6 +90,9 @@ int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream);
  * hrnet_event_create (host-side handles; no device memory). */
 #define HR_LANE_SLOT 18
 int hrnet_program_run_streams(const HrOp* ops, int n, const hr_stream_t* streams, int nstreams);
+/* Measurement form of the above: a timing event behind every op on its lane; end_ms[k] = completion of op k in
+ * ms since the call began on op 0's lane. Synchronises every stream before returning (not for the training loop). */
+int hrnet_program_run_streams_timed(const HrOp* ops, int n, const hr_stream_t* streams, int nstreams, float* end_ms);
 void* hrnet_event_create(void);
 int hrnet_event_destroy(void* event);
 
@@ -141,6 +146,16 @@ int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, floa
                           const void* bs_y, const void* bs_mask, const float* bs_scale,
                           const float* bs_shift, int N, int H, int W, int Cin, int Ho, int Wo,
                           int Cout, int ks, int stride, int upz, int accumulate, hr_stream_t stream);
+/*
+ * The 3x3 stride-1 branch convolutions (BasicBlock.conv1 / conv2, pose_hrnet.py:41-57) run as an LDS-ring
+ * pipeline (csrc/conv_ring.hip) behind hrnet_conv2d / hrnet_conv2d_bnref when the shape is served (bf16, Cin a
+ * multiple of 32, no bias / accumulate / zero-stuffing, output statistics by atomics or none). This switch turns
+ * that routing on (1, the default; environment HRNET_CONV_RING) or off (0: the tile-walking body of conv_body.h)
+ * for A/B measurements and parity tests; returns the previous setting (-1: never decided).
+ */
+int hrnet_conv_ring_enable(int on);
+int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout);
+
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,
                            int mode, char* buf, int buflen);
