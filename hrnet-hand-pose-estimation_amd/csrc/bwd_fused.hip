@@ -51,7 +51,9 @@ struct BwdArgs {
   int tiles_y, tiles_x, total_tiles;
   int ncb, nsplit;
   int in_relu, mask_out;
-  int atomic;            // the workgroups add their weight-gradient tiles into slab 0 with float atomics
+  // atomic = 1: `slabs` IS the OIHW f32 gradient [Cout_real][Cin_real][3][3]; the workgroups ADD their tiles into it
+  // with float atomics, through LDS so that a wave instruction covers 64 consecutive floats (no slabs, no reduce)
+  int atomic, Cout_real, Cin_real;
   unsigned long long* stamp;   // measurement only (HRNET_FUSED_STAMP_PTR): 32 s_memtime stamps per workgroup
   int ablate;   // measurement only (HRNET_FUSED_ABLATE): 1 skip input-gradient MFMAs, 2 skip weight-gradient MFMAs, 4 skip the
                 // epilogue's global traffic, 8 skip the tile loads (stage zeros)
@@ -536,7 +538,39 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 
   FSTAMP();
   // ---- weight-gradient slab of this workgroup: slab[split][co][tap][ci], D: col = ci, row = co ----
-  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)split * a.Cout * 9 * a.Cin);
+  if (a.atomic) {
+    // [co][ci][tap] tiles of 16 output channels through LDS (the walk ended on a barrier: the images are free)
+    __syncthreads();          // (the statistics reduction above read its scratch in the same bytes)
+    float* tl = (float*)lds;
+    static_assert(16 * CB * 9 * 4 <= GBYTES + ABYTES + WBYTES, "weight-gradient tile fits the LDS images");
+#pragma unroll
+    for (int h = 0; h < COP / 16; ++h) {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        const int fr = wn + WN * j;
+        if (fr < NFR) {
+          const int tp = fr / (CB / 16), cil = (fr % (CB / 16)) * 16 + li;
+#pragma unroll
+          for (int f = 0; f < FCOW; ++f) {
+            if (wco * FCOW + f == h) {
+              const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tl[((lg * 4 + r) * CB + cil) * 9 + tp] = v4[r];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int nci = min(CB, a.Cin_real - c0);
+      for (int idx = tid; idx < 16 * CB * 9; idx += NT) {
+        const int col = idx / (CB * 9), rem = idx - col * (CB * 9);
+        const int co = h * 16 + col;
+        if (co < a.Cout_real && rem < nci * 9) atomicAdd(a.slabs + ((size_t)co * a.Cin_real + c0) * 9 + rem, tl[idx]);
+      }
+      if (h + 1 < COP / 16) __syncthreads();
+    }
+  } else {
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int fr = wn + WN * j;
@@ -548,12 +582,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
         const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < a.Cout && ci < a.Cin) {
-            float* dst = slab + ((size_t)(co + r) * 9 + tp) * a.Cin + ci;
-            if (a.atomic) atomicAdd(dst, v4[r]); else *dst = v4[r];
-          }
+          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * 9 + tp) * a.Cin + ci] = v4[r];
       }
     }
+  }
   }
   FSTAMP();
 }
@@ -642,7 +674,8 @@ extern "C" int hrnet_conv3x3_bwd_fused(int dtype, const void* dz, const void* y,
 static int bwd_fused_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
                             const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
                             void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
-                            int N, int H, int W, int Cin, int Cout, int atomic, hr_stream_t stream);
+                            int N, int H, int W, int Cin, int Cout, int atomic, int Cout_real, int Cin_real,
+                            hr_stream_t stream);
 
 extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const void* y, const float* coef,
                                              const HrBnBwdRef* ref, const void* x, const float* in_scale,
@@ -651,13 +684,16 @@ extern "C" int hrnet_conv3x3_bwd_fused_bnref(int dtype, const void* dz, const vo
                                              float* slabs, int N, int H, int W, int Cin, int Cout,
                                              hr_stream_t stream) {
   return bwd_fused_launch(dtype, dz, y, coef, ref, x, in_scale, in_shift, in_relu, wT, dx, addend, mask_out, rows, bs_y,
-                          slabs, N, H, W, Cin, Cout, 0, stream);
+                          slabs, N, H, W, Cin, Cout, 0, 0, 0, stream);
 }
 
 static int bwd_fused_launch(int dtype, const void* dz, const void* y, const float* coef, const HrBnBwdRef* ref,
                             const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* wT,
                             void* dx, const void* addend, int mask_out, float* rows, const void* bs_y, float* slabs,
-                            int N, int H, int W, int Cin, int Cout, int atomic, hr_stream_t stream) {
+                            int N, int H, int W, int Cin, int Cout, int atomic, int Cout_real, int Cin_real,
+                            hr_stream_t stream) {
+  HR_REQUIRE(!atomic || (Cout_real >= 1 && Cout_real <= Cout && Cin_real >= 1 && Cin_real <= Cin),
+             "bwd_fused: the atomic form needs the gradient's real channel counts (%d, %d)", Cout_real, Cin_real);
   HR_REQUIRE(hrnet_bwd_fused_supported(dtype, Cin, Cout), "bwd_fused: dtype %d Cin %d Cout %d not served", dtype, Cin, Cout);
   HR_REQUIRE(dz && x && wT && dx && slabs, "bwd_fused: null pointer");
   HR_REQUIRE((!coef && !ref) || y, "bwd_fused: coef needs y");
@@ -679,7 +715,7 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
   a.ncb = (Cin + 31) / 32;
   a.nsplit = hrnet_bwd_fused_splits(dtype, N, H, W, Cin, Cout);
   a.in_relu = in_relu; a.mask_out = mask_out;
-  a.atomic = atomic;
+  a.atomic = atomic; a.Cout_real = Cout_real; a.Cin_real = Cin_real;
   { static const char* sp = getenv("HRNET_FUSED_STAMP_PTR"); a.stamp = sp ? (unsigned long long*)strtoull(sp, nullptr, 16) : nullptr; }
   { static const int abl = getenv("HRNET_FUSED_ABLATE") ? atoi(getenv("HRNET_FUSED_ABLATE")) : 0; a.ablate = abl; }
   const unsigned grid = (unsigned)((a.nsplit + 7) / 8 * 8 * a.ncb);
@@ -698,9 +734,10 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
 }
 
 int hr_launch_bwd_fused(const HrOp& op, hipStream_t s) {
-  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8]: weight-gradient tiles by atomics
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8] = 1: p[11] is the OIHW gradient the
+  // weight-gradient tiles are ADDED to (float atomics), i[9], i[10] its real Cout, Cin
   return bwd_fused_launch(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12], op.p[3],
                           (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7],
                           (float*)op.p[9], op.p[10], (float*)op.p[11], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5],
-                          op.i[8], (hr_stream_t)s);
+                          op.i[8], op.i[9], op.i[10], (hr_stream_t)s);
 }

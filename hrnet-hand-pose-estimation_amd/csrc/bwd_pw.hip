@@ -39,7 +39,7 @@ struct PwArgs {
   float* slabs;          // [nsplit][Cout][Cin] f32
   long long P;
   int total_tiles, nsplit;
-  int atomic;            // the workgroups add their weight-gradient tiles into slab 0 with float atomics
+  int atomic;            // `slabs` IS the [Cout][Cin] f32 gradient: the workgroups ADD their tiles into it (float atomics)
   int in_relu, mask_out;
 };
 
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
   }
 
   // ---- weight-gradient slab of this workgroup: slab[split][co][ci] ----
-  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)split * CO * CI);
+  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)split * CO * CI);   // (no channel padding at these widths)
 #pragma unroll
   for (int f = 0; f < FCOW; ++f)
 #pragma unroll
@@ -453,6 +453,7 @@ static int bwd_pw_launch(int dtype, const void* dz, const void* y, const float* 
   a.total_tiles = (int)((pixels + 63) / 64);
   a.nsplit = hrnet_bwd_pw_splits(dtype, pixels, Cin, Cout);
   a.in_relu = in_relu; a.mask_out = mask_out;
+  HR_REQUIRE(atomic >= 0, "bwd_pw: the atomic form serves unpadded layers (real channel counts = tensor channel counts)");
   a.atomic = atomic;
   hipStream_t s = (hipStream_t)stream;
   switch (pw_shape(Cin, Cout)) {
@@ -466,9 +467,10 @@ static int bwd_pw_launch(int dtype, const void* dz, const void* y, const float* 
 // op slots as OP_BWD_FUSED (p[0..11] = dz,y,coef,x,scale,shift,wT,dx,addend,rows,bs_y,slabs;
 // i[0..7] = dtype,N,H,W,Cin,Cout,in_relu,mask_out)
 int hr_launch_bwd_pw(const HrOp& op, hipStream_t s) {
-  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8]: weight-gradient tiles by atomics
+  // p[12]: HOST pointer to a HrBnBwdRef (kept alive by the plan), or NULL; i[8] = 1: p[11] is the [Cout][Cin] gradient
+  // the weight-gradient tiles are ADDED to (float atomics; i[9], i[10] = its real Cout, Cin: must equal the tensors')
   return bwd_pw_launch(op.i[0], op.p[0], op.p[1], (const float*)op.p[2], (const HrBnBwdRef*)op.p[12], op.p[3],
                        (const float*)op.p[4], (const float*)op.p[5], op.i[6], op.p[6], op.p[7], op.p[8], op.i[7],
                        (float*)op.p[9], op.p[10], (float*)op.p[11], (long long)op.i[1] * op.i[2] * op.i[3], op.i[4],
-                       op.i[5], op.i[8], (hr_stream_t)s);
+                       op.i[5], (op.i[8] && op.i[9] == op.i[5] && op.i[10] == op.i[4]) ? 1 : (op.i[8] ? -1 : 0), (hr_stream_t)s);
 }

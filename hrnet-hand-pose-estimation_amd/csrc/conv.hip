@@ -15,14 +15,19 @@ inline int conv_mode(const ConvArgs& a, bool in_relu) {
   return CONV_GENERIC;
 }
 
-// forward 3x3 stride-1 launches conv_ring.hip serves: no bias / accumulate / zero-stuffing / backward statistics,
-// output statistics by atomics (or none), the input's BatchNorm as sums or arrays (or a raw input)
-inline bool ring_serves(const ConvArgs& a, int dtype, int ks, int stride, int mode) {
-  if (ks != 3 || stride != 1 || a.upz || a.accumulate || a.bias || a.bs_y || a.in_dy || a.in_dx) return false;
-  if (mode != CONV_FWD && mode != CONV_GENERIC && mode != CONV_DG) return false;
-  if (a.stats && !a.stats_atomic) return false;
-  if (a.in_sums && a.in_beta != a.in_gamma + a.Cin) return false;
-  return hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, a.N, a.H, a.W, a.Cin, a.Cout) != 0;
+// 3x3 stride-1 launches conv_ring.hip serves. Forward: no bias / accumulate / zero-stuffing, output statistics by
+// atomics (or none), the input's BatchNorm as sums or arrays (or a raw input). Input gradient (returns 2): raw
+// input, optional accumulation into y, optional backward statistics (rows: hrnet_conv_rows_bwdstats()).
+inline int ring_serves(const ConvArgs& a, int dtype, int ks, int stride, int mode, bool in_relu) {
+  if (ks != 3 || stride != 1 || a.upz || a.bias || a.in_dy || a.in_dx || !hr_conv_ring_enabled()) return 0;
+  const bool raw = !a.in_scale && !a.in_sums && !in_relu;
+  if (mode == CONV_BS || (raw && a.accumulate && !a.stats))
+    return hr_conv_ring_supported(dtype, a.N, a.H, a.W, a.Cin, a.Cout, 1) ? 2 : 0;
+  if (a.accumulate || a.bs_y) return 0;
+  if (mode != CONV_FWD && mode != CONV_GENERIC && mode != CONV_DG) return 0;
+  if (a.stats && !a.stats_atomic) return 0;
+  if (a.in_sums && a.in_beta != a.in_gamma + a.Cin) return 0;
+  return hr_conv_ring_supported(dtype, a.N, a.H, a.W, a.Cin, a.Cout, 0) ? 1 : 0;
 }
 
 inline int launch_ring(const ConvArgs& a, int in_relu, hipStream_t s) {
@@ -30,7 +35,9 @@ inline int launch_ring(const ConvArgs& a, int in_relu, hipStream_t s) {
   c.x = a.x; c.w = a.w; c.y = a.y;
   c.in_sums = a.in_sums; c.in_gb = a.in_gamma; c.in_scale = a.in_scale; c.in_shift = a.in_shift;
   c.stats = a.stats; c.in_inv_count = a.in_inv_count; c.in_eps = a.in_eps;
+  c.bs_y = a.bs_y; c.bs_mask = a.bs_mask; c.bs_scale = a.bs_scale; c.bs_shift = a.bs_shift;
   c.N = a.N; c.H = a.H; c.W = a.W; c.Cin = a.Cin; c.Cout = a.Cout; c.in_relu = in_relu;
+  c.accumulate = a.accumulate; c.bs_store_masked = a.bs_store_masked;
   return hr_conv_ring_launch(c, s);
 }
 }  // namespace
@@ -41,6 +48,14 @@ extern "C" int hrnet_conv_tiles(int N, int Ho, int Wo, int Cout, int ks, int str
 
 extern "C" int hrnet_conv_tiles_bwdstats(int N, int Ho, int Wo, int Cout, int ks, int stride) {
   return choose_tile(N, Ho, Wo, Cout, ks, stride, true, ks == 3 && stride == 2).gx;
+}
+
+// statistics rows hrnet_conv2d_bwdstats writes for this launch (the kernel family is chosen per dtype and shape:
+// the LDS-ring pipeline leaves one row per pixel walk of ITS grid)
+extern "C" int hrnet_conv_rows_bwdstats(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride) {
+  if (ks == 3 && stride == 1 && hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout, 1))
+    return hr_conv_ring_rows(N, Ho, Wo, Cin, Cout);
+  return hrnet_conv_tiles_bwdstats(N, Ho, Wo, Cout, ks, stride);
 }
 
 // the tile walk a conv launch of this shape takes: out5 = {tile height, tile width, output-channel block,
@@ -103,7 +118,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(!a.in_sums || mode == CONV_FWD || mode == CONV_FWDB,
              "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
   // the branch 3x3 convolutions: LDS-ring pipeline (conv_ring.hip)
-  if (ring_serves(a, dtype, ks, op.i[9], mode)) return launch_ring(a, op.i[11], s);
+  if (ring_serves(a, dtype, ks, op.i[9], mode, op.i[11] != 0)) return launch_ring(a, op.i[11], s);
   // the GEMM-shaped head layer (and its input gradient): every output channel of a pixel block in one workgroup
   if (ks == 1 && stride == 1 && !upz && !a.accumulate && !a.bs_y && !a.in_scale && !a.in_sums && !op.i[11] &&
       (!a.stats || a.stats_atomic) && !a.in_dy && !a.in_dx && hr_gemm_pw_supported(dtype, Cin, Cout))
@@ -287,9 +302,12 @@ extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin,
   if (ks == 1 && stride == 1 && !upz && hr_gemm_pw_supported(dtype, Cin, Cout) &&
       (mode == CONV_FWD || mode == CONV_FWDB || mode == CONV_DG))
     return snprintf(buf, buflen, "gemm_pw_kernel");
-  if (ks == 3 && stride == 1 && !upz && (mode == CONV_FWD || mode == CONV_GENERIC || mode == CONV_DG) &&
-      hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout))
-    return hr_conv_ring_name(hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout), buf, buflen);
+  if (ks == 3 && stride == 1 && !upz && hr_conv_ring_enabled()) {
+    const int bsm = mode == CONV_BS ? 1 : 0;
+    if ((bsm || mode == CONV_FWD || mode == CONV_GENERIC || mode == CONV_DG) &&
+        hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout, bsm))
+      return hr_conv_ring_name(hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout, bsm), bsm, buf, buflen);
+  }
   const bool s2d = upz && (mode == CONV_BS || mode == CONV_DG);
   const TileChoice tc = choose_tile(N, Ho, Wo, Cout, ks, stride, mode == CONV_BS, s2d);
   static const int wp[8] = {4, 2, 2, 2, 2, 0, 4, 2}, wc[8] = {1, 2, 2, 2, 2, 0, 1, 2};

@@ -12,14 +12,22 @@ struct HrRingConv {
   const float* in_gb;
   const float* in_scale;  // or scale / shift arrays, or neither (raw input)
   const float* in_shift;
-  float* stats;           // [8][2][Cout] batch sums of the output (float atomics) or NULL
+  float* stats;           // forward: [8][2][Cout] batch sums of the output (float atomics) or NULL;
+                          // backward statistics: rows [hr_conv_ring_rows()][2][Cout]
+  const void* bs_y;       // backward-statistics operands (hrnet_conv2d_bwdstats), or NULL
+  const void* bs_mask;
+  const float* bs_scale;
+  const float* bs_shift;
   float in_inv_count, in_eps;
-  int N, H, W, Cin, Cout, in_relu;
+  int N, H, W, Cin, Cout, in_relu, accumulate, bs_store_masked;
 };
 
 int hr_conv_ring_enabled();
-// instantiation id (> 0) if conv_ring serves a 3x3 stride-1 pad-1 launch of this shape, else 0
-int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout);
+// instantiation id (> 0) if conv_ring serves a 3x3 stride-1 pad-1 launch of this shape, else 0.
+// bs: an input-gradient launch (raw input) with backward statistics and / or accumulation into y
+int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout, int bs);
+// statistics rows a backward-statistics launch of this shape writes (= its pixel walks)
+int hr_conv_ring_rows(int N, int H, int W, int Cin, int Cout);
 int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s);
 // name of instantiation `id` as rocprofv3 prints it (returns its length)
-int hr_conv_ring_name(int id, char* buf, int buflen);
+int hr_conv_ring_name(int id, int bs, char* buf, int buflen);

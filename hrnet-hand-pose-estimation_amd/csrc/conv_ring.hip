@@ -41,11 +41,17 @@ struct RingArgs {
   const float* in_gb;    // gamma[Cin] | beta[Cin] (contiguous), with in_sums
   const float* in_scale; // or: precomputed scale / shift arrays
   const float* in_shift;
-  float* stats;          // [8][2][Cout] (atomic) or NULL
+  float* stats;          // forward: [8][2][Cout] batch sums (atomic) or NULL; backward statistics: rows [gx][2][Cout]
+  // backward-statistics launches (an input gradient whose output is the gradient of a BatchNorm'ed activation):
+  // rows get (sum dz, sum dz*bs_y), dz = v * [m > 0], m = bs_mask (or bs_y) mapped through bs_scale/bs_shift
+  const char* bs_y;
+  const char* bs_mask;
+  const float* bs_scale;
+  const float* bs_shift;
   float in_inv_count, in_eps;
   int N, H, W, Cin, Cout;
   int tiles_y, tiles_x, total_tiles, tpw, gx, gy;
-  int in_relu;
+  int in_relu, accumulate, bs_store_masked;
   unsigned x_bytes, y_bytes, w_bytes;
 #ifdef HR_RING_STAMP
   unsigned long long* stamp;   // measurement build only: 32 s_memrealtime stamps per workgroup
@@ -71,12 +77,16 @@ __device__ __forceinline__ void lds_barrier() {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB = 0x80000000u;   // beyond every buffer's num_records: reads return 0, stores are dropped
 
-// TH x TW output pixels per tile, NB output channels per workgroup, NW waves as WPX (pixel groups) x NW/WPX
-// (channel groups), R ring slots, WCH > 0: the weights of all WCH input-channel chunks stay resident
-template <int TH, int TW, int NB, int NW, int WPX, int R, int WCH>
+// A tile = TI images x TH x TW output pixels (TI > 1: whole images, TH x TW = the map), NB output channels per
+// workgroup, NW waves as WPX (pixel groups) x NW/WPX (channel groups), R ring slots, WCH > 0: the weights of all
+// WCH input-channel chunks stay resident (else one weight chunk travels with every stage).
+// Halo rows are stored with a pitch of TW + 2 pixels (TW = 16) or 16 pixels (TW = 8: the two rows a pixel fragment
+// spans then sit on complementary bank slots, and a 1 KiB piece is exactly one halo row).
+template <int TH, int TW, int TI, int NB, int NW, int WPX, int R, int WCH>
 struct RingCfg {
   static constexpr int NT = NW * 64;
-  static constexpr int HH = TH + 2, HW = TW + 2, HPX = HH * HW;
+  static constexpr int HH = TH + 2, HW = TW + 2, HWP = TW == 8 ? 16 : HW;
+  static constexpr int IPX = HH * HWP, HPX = TI * IPX;   // pixel slots per image / per tile
   static constexpr int NPX = (HPX + 15) / 16;            // 1 KiB pieces of a halo chunk
   static constexpr int XSB = HPX * 64;                   // bytes of one ring slot's input image
   static constexpr int NPWC = NB * 9 / 16;               // pieces of one weight chunk
@@ -84,30 +94,28 @@ struct RingCfg {
   static constexpr bool WRES = WCH > 0;
   static constexpr int KPX = (NPX + NW - 1) / NW;        // pieces per wave
   static constexpr int KPW = (NPWC + NW - 1) / NW;
-  static constexpr int NPF = TH * TW / 16, NCF = NB / 16, WCO = NW / WPX;
+  static constexpr int TPX = TH * TW;                    // output pixels per image of the tile
+  static constexpr int NPF = TI * TPX / 16, NCF = NB / 16, WCO = NW / WPX;
   static constexpr int FP = NPF / WPX, FC = NCF / WCO, CN = FC * 16, LANE_C = 4 * FC;
-  static constexpr int RPF = 16 / TW;                    // tile rows per pixel fragment (1 or 2)
-  static constexpr int NRO = RPF * FP + 2;               // halo rows a wave's fragments touch
   static constexpr int CMAX = WRES ? WCH * 32 : HR_RING_MAXC;
   static constexpr int XOFF = 0, WOFF = R * XSB, TOFF = WOFF + (WRES ? WCH : R) * WCB;
   static constexpr int LDSB = TOFF + 2 * CMAX * 4;
   static_assert(TW == 16 || TW == 8, "a pixel fragment is one row of 16 or two rows of 8");
   static_assert(NPF % WPX == 0 && NCF % WCO == 0 && WPX * WCO == NW, "wave grid");
-  static_assert(NB * 9 % 16 == 0, "whole weight pieces");
+  static_assert(NB * 9 % 16 == 0 && XSB % 256 == 0, "whole weight pieces; bank-aligned slots");
   static_assert(R >= 2 && R <= 4, "ring slots");
   static_assert(LDSB <= 160 * 1024, "LDS");
-  // the batch sums of the input BatchNorm are staged in the last ring slot (first used by the stage issued in
-  // the first iteration, after the table is built): 18 floats per channel
-  static_assert(CMAX * 18 * 4 <= XSB + (WRES ? 0 : WCB) || true, "sums staging");
+  static_assert(LANE_C == 8 || LANE_C == 16, "a lane stores 16-byte vectors");
 };
 
-template <int TH, int TW, int NB, int NW, int WPX, int R, int WCH>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(RingArgs a) {
-  using C = RingCfg<TH, TW, NB, NW, WPX, R, WCH>;
+template <int TH, int TW, int TI, int NB, int NW, int WPX, int R, int WCH, bool BS>
+__global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
+  using C = RingCfg<TH, TW, TI, NB, NW, WPX, R, WCH>;
   __shared__ __attribute__((aligned(1024))) char lds[C::LDSB];
   char* xl = lds + C::XOFF;
   char* wl = lds + C::WOFF;
   float* bntab = (float*)(lds + C::TOFF);     // [scale Cin][shift Cin]
+  const unsigned lds_x0 = (unsigned)(uintptr_t)(LDS_AS char*)xl;   // LDS byte address of the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,26 +141,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
   const int tile0 = wg_p * a.tpw;
   const int ntile = min(a.tpw, a.total_tiles - tile0);
   const int S = ntile * nch;
-  const bool from_sums = a.in_sums != nullptr;
-  const bool xf = from_sums || a.in_scale != nullptr || a.in_relu != 0;   // the input needs the in-place transform
-  const bool has_aff = from_sums || a.in_scale != nullptr;
-  const bool in_relu = a.in_relu != 0;
+  const bool from_sums = BS ? false : a.in_sums != nullptr;
+  const bool has_aff = BS ? false : (from_sums || a.in_scale != nullptr);
+  const bool in_relu = BS ? false : a.in_relu != 0;
+  const bool xf = has_aff || in_relu;       // the input needs the in-place transform
 
   const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
   const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)a.y_bytes, 0x00020000);
 
-  // ---- per-lane constants of the direct loads: lane j of a piece = 16-byte slot j: pixel j>>2 of the piece,
-  // chunk position j&3, which holds channel chunk cj (fixed per lane: pieces start at multiples of 16 pixels)
+  // ---- per-lane constants of the direct loads: lane j of a piece = 16-byte slot j: pixel slot j>>2 of the piece,
+  // chunk position j&3, which holds channel chunk cj (fixed per lane: pieces start at multiples of 16 slots)
   const int pj = lane >> 2, cj = (lane & 3) ^ ((pj >> 1) & 2);
-  const int pixB = a.Cin * 2, rowB = a.W * pixB;
+  const int pixB = a.Cin * 2, rowB = a.W * pixB, imgB = a.H * rowB;
+  // packed per piece: bit 31 = not a halo pixel of the tile; [29:20] image of the tile, [19:10] halo row, [9:0] column
   int hyx[C::KPX], goff[C::KPX];
 #pragma unroll
   for (int k = 0; k < C::KPX; ++k) {
     const int P = (wv + k * NW) * 16 + pj;
-    const int hy = P / C::HW, hx = P - hy * C::HW;
-    hyx[k] = P < C::HPX ? (hy << 16) | hx : (0x4000 << 16);      // beyond the halo: a row far outside
-    goff[k] = hy * rowB + hx * pixB + cj * 16;
+    const int img = P / C::IPX, r = P - img * C::IPX;
+    const int hy = r / C::HWP, hx = r - hy * C::HWP;
+    hyx[k] = (P < C::HPX && hx < C::HW) ? (img << 20) | (hy << 10) | hx : (int)0x80000000;
+    goff[k] = img * imgB + hy * rowB + hx * pixB + cj * 16;
   }
   // weight pieces: row (tap, co) of the chunk image; LDS column co holds the channel the MFMA row order needs
   int woff[C::KPW];
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
     return v;
   };
 
-  // tile cursors: issue (loads), transform, compute; each walks (tile, chunk) in the same order
+  // tile cursors: issue (loads), transform, compute; each walks (tile, chunk) in the same order. n counts groups
+  // of TI images.
   struct Cur { int n, ty, tx, ch; };
   auto cur_init = [&](Cur& c) {
     int bq = tile0;
@@ -195,6 +206,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
   };
   Cur ci, ct, cc;
   cur_init(ci); cur_init(ct); cur_init(cc);
+
+  // is halo pixel (packed h) of the tile at (n, iy0, ix0) inside the tensor?
+  auto inside = [&](int h, int n, int iy0, int ix0) {
+    const int gy = iy0 + ((h >> 10) & 0x3ff), gx = ix0 + (h & 0x3ff);
+    return h >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && n * TI + (h >> 20) < a.N;
+  };
 
   auto issue_w = [&](int chunk, int slot_or_chunk) {     // one weight chunk image
 #pragma unroll
@@ -212,15 +229,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
     const int n = __builtin_amdgcn_readfirstlane(ci.n), ty = __builtin_amdgcn_readfirstlane(ci.ty),
               tx = __builtin_amdgcn_readfirstlane(ci.tx), ch = __builtin_amdgcn_readfirstlane(ci.ch);
     const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
-    const int sbase = ((n * a.H + iy0) * a.W + ix0) * pixB + ch * 64;     // may be negative: only valid lanes use it
+    const int sbase = ((n * TI * a.H + iy0) * a.W + ix0) * pixB + ch * 64;     // may be negative: only valid lanes use it
 #pragma unroll
     for (int k = 0; k < C::KPX; ++k) {
       const int q = wv + k * NW;
       if (q < C::NPX) {
-        const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
-        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const unsigned vo = ok ? (unsigned)(sbase + goff[k]) : OOB;
-        if ((hyx[k] >> 16) < C::HH)     // (only the last piece has lanes beyond the halo: they stay out of the next slot)
+        const unsigned vo = inside(hyx[k], n, iy0, ix0) ? (unsigned)(sbase + goff[k]) : OOB;
+        // (slots beyond the tile's halo stay out of the next ring slot; padding slots of a row get zeros)
+        if ((q * 16 + pj) < C::HPX)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xl + slot * C::XSB + q * 1024), 16, vo, 0, 0, 0);
         ++cnt;
       }
@@ -229,6 +245,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
     set_mark(slot, cnt);
     cur_next(ci);
   };
+
+  // backward-statistics coefficients of this lane's channels (plain loads, issued before any direct load)
+  const int cbase = n0 + wco * C::CN + lg * C::LANE_C;
+  const bool cok = cbase < a.Cout;
+  float bsc[BS ? C::LANE_C : 1], bsh[BS ? C::LANE_C : 1];
+  if constexpr (BS) {
+#pragma unroll
+    for (int k = 0; k < C::LANE_C; ++k) {
+      bsc[k] = (a.bs_scale && cok) ? a.bs_scale[cbase + k] : 1.f;
+      bsh[k] = (a.bs_scale && cok) ? a.bs_shift[cbase + k] : 0.f;
+    }
+  }
 
   // ---- prologue: the BatchNorm inputs (into the last ring slot), resident weights, the first R-1 stages ----
   char* stg = xl + (R - 1) * C::XSB;                    // staging: [8][2][Cin] sums | gamma | beta  (or scale | shift)
@@ -244,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stg + q * 1024), 16, (unsigned)(q * 1024 + lane * 16), 0, 0, 0);
         ++cnt;
       }
-      const int go = from_sums ? a.Cin * 64 : a.Cin * 4;    // multiples of 1 KiB for Cin % 16 == 0 (sums) / 256 (arrays)
+      const int go = from_sums ? a.Cin * 64 : a.Cin * 4;
       const int ng = ((from_sums ? 2 : 1) * a.Cin * 4 + 1023) / 1024;
       for (int q = 0; q < ng; ++q) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(stg + ((go + 1023) & ~1023) + q * 1024), 16,
@@ -282,16 +310,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
   }
   RSTAMP();
 
-  // ---- per-lane MFMA operand offsets ----
-  int boff[C::NRO * 3];
+  // ---- per-lane MFMA operand offsets: halo slot of this lane's pixel of fragment fp, shifted by tap (dy, dx) ----
+  int boff[C::FP][9];
 #pragma unroll
-  for (int r = 0; r < C::NRO; ++r)
+  for (int fp = 0; fp < C::FP; ++fp) {
+    const int p = (wpx * C::FP + fp) * 16 + li;
+    const int img = p / C::TPX, q = p - img * C::TPX;
+    const int oy = q / TW, ox = q - oy * TW;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      // halo pixel of lane li for the fragment whose first tile row is (r - dy): row r of the wave's halo window
-      const int P = (wpx * C::FP * C::RPF + r + (C::RPF == 2 ? (li >> 3) : 0)) * C::HW + (C::RPF == 2 ? (li & 7) : li) + dx;
-      boff[r * 3 + dx] = P * 64 + ((lg ^ ((P >> 1) & 2)) << 4);
+    for (int tp = 0; tp < 9; ++tp) {
+      const int P = img * C::IPX + (oy + tp / 3) * C::HWP + ox + tp % 3;
+      boff[fp][tp] = P * 64 + ((lg ^ ((P >> 1) & 2)) << 4);
     }
+  }
   int aoff[C::FC];
 #pragma unroll
   for (int fc = 0; fc < C::FC; ++fc) {
@@ -319,7 +350,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
     const int slot = s % R;
     const int n = __builtin_amdgcn_readfirstlane(ct.n), ty = __builtin_amdgcn_readfirstlane(ct.ty),
               tx = __builtin_amdgcn_readfirstlane(ct.tx), ch = __builtin_amdgcn_readfirstlane(ct.ch);
-    (void)n;
     if (xf) {
       if (nch != 1) load_coef(ch);
       const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
@@ -327,12 +357,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
       for (int k = 0; k < C::KPX; ++k) {
         const int q = wv + k * NW;
         if (q < C::NPX) {
-          const int gy = iy0 + (hyx[k] >> 16), gx = ix0 + (hyx[k] & 0xffff);
-          const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-          if ((hyx[k] >> 16) < C::HH) {
-            V16* p = (V16*)(xl + slot * C::XSB + q * 1024 + lane * 16);
+          const bool ok = inside(hyx[k], n, iy0, ix0);
+          if ((q * 16 + pj) < C::HPX) {
+            // (LDS accesses in inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of a ds_read of the address a
+            // direct load wrote - it would drain the younger stages; the data is this lane's own and the counted
+            // wait above covers it)
+            const unsigned la = lds_x0 + (unsigned)(slot * C::XSB + q * 1024 + lane * 16);
+            V16 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(la) : "memory");
             float f[8];
-            v16_unpack<bf16_t>(*p, f);
+            v16_unpack<bf16_t>(v, f);
             if (in_relu) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) { f[j] = fmaf(f[j], sc[j], sh[j]); f[j] = f[j] > 0.f ? f[j] : 0.f; }
@@ -340,7 +374,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
 #pragma unroll
               for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
             }
-            *p = ok ? v16_pack<bf16_t>(f) : v16_zero();
+            v = ok ? v16_pack<bf16_t>(f) : v16_zero();
+            asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(v) : "memory");
           }
         }
       }
@@ -348,11 +383,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
     cur_next(ct);
   };
 
-  const int cbase = n0 + wco * C::CN + lg * C::LANE_C;
-  const bool cok = cbase < a.Cout;
   float s1[C::LANE_C], s2[C::LANE_C];
 #pragma unroll
   for (int k = 0; k < C::LANE_C; ++k) s1[k] = s2[k] = 0.f;
+  constexpr int LV = C::LANE_C / 8;           // 16-byte vectors of a lane's channels
 
   if (S > 0) {
     wait_vmcnt(cnt - get_mark(0));
@@ -365,67 +399,128 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
   f32x4 acc[C::FC][C::FP];
   for (int i = 0; i < S; ++i) {
     if (i + R - 1 < S) issue_stage(i + R - 1);
-    if (i + 1 < S) {
-      wait_vmcnt(cnt - get_mark((i + 1) % R));
-      RSTAMP();
-      transform(i + 1);
+    if constexpr (R > 2) {
+      // the stage after this one is transformed before this one's matrix work (its loads were issued two iterations ago)
+      if (i + 1 < S) {
+        wait_vmcnt(cnt - get_mark((i + 1) % R));
+        RSTAMP();
+        transform(i + 1);
+      }
     }
     RSTAMP();
     const int ch = __builtin_amdgcn_readfirstlane(cc.ch);
+    const int n = __builtin_amdgcn_readfirstlane(cc.n), ty = __builtin_amdgcn_readfirstlane(cc.ty),
+              tx = __builtin_amdgcn_readfirstlane(cc.tx);
     if (ch == 0) {
 #pragma unroll
       for (int fc = 0; fc < C::FC; ++fc)
 #pragma unroll
         for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // epilogue operands of a backward-statistics / accumulating launch: plain loads, issued with the tile's last
+    // stage (the wide layers these launches serve have one tile per workgroup: nothing is left in the ring)
+    V16 pre_y[BS ? C::FP : 1][LV], pre_m[BS ? C::FP : 1][LV], pre_o[BS ? C::FP : 1][LV];
+    if constexpr (BS) {
+      if (ch == nch - 1) {
+        const auto rby = __builtin_amdgcn_make_buffer_rsrc((void*)a.bs_y, 0, (int)a.y_bytes, 0x00020000);
+        const auto rbm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bs_mask ? a.bs_mask : a.bs_y), 0, (int)a.y_bytes, 0x00020000);
+#pragma unroll
+        for (int fp = 0; fp < C::FP; ++fp) {
+          const int p = (wpx * C::FP + fp) * 16 + li;
+          const int img = p / C::TPX, q = p - img * C::TPX;
+          const int oy = ty * TH + q / TW, ox = tx * TW + q % TW, ni = n * TI + img;
+          const bool pok = cok && oy < a.H && ox < a.W && ni < a.N;
+          const unsigned vo = pok ? (unsigned)((((ni * a.H + oy) * a.W + ox) * a.Cout + cbase) * 2) : OOB;
+#pragma unroll
+          for (int v = 0; v < LV; ++v) {
+            pre_y[fp][v] = a.bs_y ? __builtin_amdgcn_raw_buffer_load_b128(rby, pok ? vo + v * 16 : OOB, 0, 0) : v16_zero();
+            pre_m[fp][v] = a.bs_mask ? __builtin_amdgcn_raw_buffer_load_b128(rbm, pok ? vo + v * 16 : OOB, 0, 0) : v16_zero();
+            pre_o[fp][v] = a.accumulate ? __builtin_amdgcn_raw_buffer_load_b128(ry, pok ? vo + v * 16 : OOB, 0, 0) : v16_zero();
+          }
+        }
+        cnt += C::FP * LV * ((a.bs_y ? 1 : 0) + (a.bs_mask ? 1 : 0) + (a.accumulate ? 1 : 0));
+      }
+    }
     const char* xs = xl + (i % R) * C::XSB;
     const char* ws = wl + (C::WRES ? ch : i % R) * C::WCB;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
-      const int dy = tp / 3, dx = tp % 3;
       V16 af[C::FC], bf[C::FP];
 #pragma unroll
       for (int fc = 0; fc < C::FC; ++fc) af[fc] = *(const V16*)(ws + aoff[fc] + tp * NB * 64);
 #pragma unroll
-      for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xs + boff[(fp * C::RPF + dy) * 3 + dx]);
+      for (int fp = 0; fp < C::FP; ++fp) bf[fp] = *(const V16*)(xs + boff[fp][tp]);
 #pragma unroll
       for (int fc = 0; fc < C::FC; ++fc)
 #pragma unroll
         for (int fp = 0; fp < C::FP; ++fp) acc[fc][fp] = mma16<bf16_t>(af[fc], bf[fp], acc[fc][fp]);
     }
     RSTAMP();
+    if constexpr (R == 2) {
+      // two slots: the next stage lands while this one's matrix work runs, and is transformed after it
+      if (i + 1 < S) {
+        wait_vmcnt(cnt - get_mark((i + 1) % R));
+        transform(i + 1);
+      }
+    }
     if (ch == nch - 1) {
       // ---- tile epilogue: 4*FC contiguous output channels per pixel, statistics ----
-      const int n = __builtin_amdgcn_readfirstlane(cc.n), ty = __builtin_amdgcn_readfirstlane(cc.ty),
-                tx = __builtin_amdgcn_readfirstlane(cc.tx);
 #pragma unroll
       for (int fp = 0; fp < C::FP; ++fp) {
         const int p = (wpx * C::FP + fp) * 16 + li;
-        const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
-        const bool pok = cok && oy < a.H && ox < a.W;
+        const int img = p / C::TPX, q = p - img * C::TPX;
+        const int oy = ty * TH + q / TW, ox = tx * TW + q % TW, ni = n * TI + img;
+        const bool pok = cok && oy < a.H && ox < a.W && ni < a.N;
         float vals[C::LANE_C];
 #pragma unroll
         for (int fc = 0; fc < C::FC; ++fc) {
           vals[fc * 4 + 0] = acc[fc][fp].x; vals[fc * 4 + 1] = acc[fc][fp].y;
           vals[fc * 4 + 2] = acc[fc][fp].z; vals[fc * 4 + 3] = acc[fc][fp].w;
         }
-        if (pok) {
+        if constexpr (!BS) {
+          if (pok) {
 #pragma unroll
-          for (int k = 0; k < C::LANE_C; ++k) {
-            s1[k] += vals[k];
-            s2[k] += vals[k] * vals[k];
-          }
-        }
-        const unsigned vo = pok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + cbase) * 2) : OOB;
-        if constexpr (C::LANE_C >= 8) {
-#pragma unroll
-          for (int k0 = 0; k0 < C::LANE_C; k0 += 8) {
-            __builtin_amdgcn_raw_buffer_store_b128(v16_pack<bf16_t>(vals + k0), ry, pok ? vo + k0 * 2 : OOB, 0, 0);
-            ++cnt;
+            for (int k = 0; k < C::LANE_C; ++k) {
+              s1[k] += vals[k];
+              s2[k] += vals[k] * vals[k];
+            }
           }
         } else {
-          const bf16x4 o = {(bf16_t)vals[0], (bf16_t)vals[1], (bf16_t)vals[2], (bf16_t)vals[3]};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, vo, 0, 0);
+          if (a.accumulate) {
+            float old[C::LANE_C];
+#pragma unroll
+            for (int v = 0; v < LV; ++v) v16_unpack<bf16_t>(pre_o[fp][v], old + v * 8);
+#pragma unroll
+            for (int k = 0; k < C::LANE_C; ++k) vals[k] += old[k];
+          }
+          if (a.bs_y && pok) {
+            // vals hold the finished gradient of this output element
+            float yv[C::LANE_C], mv[C::LANE_C];
+#pragma unroll
+            for (int v = 0; v < LV; ++v) v16_unpack<bf16_t>(pre_y[fp][v], yv + v * 8);
+            if (a.bs_mask) {
+#pragma unroll
+              for (int v = 0; v < LV; ++v) v16_unpack<bf16_t>(pre_m[fp][v], mv + v * 8);
+#pragma unroll
+              for (int k = 0; k < C::LANE_C; ++k) mv[k] = fmaf(mv[k], bsc[k], bsh[k]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < C::LANE_C; ++k) mv[k] = fmaf(yv[k], bsc[k], bsh[k]);
+            }
+            const bool masked = a.bs_mask || a.bs_scale;
+#pragma unroll
+            for (int k = 0; k < C::LANE_C; ++k) {
+              const float dz = (!masked || mv[k] > 0.f) ? vals[k] : 0.f;
+              s1[k] += dz;
+              s2[k] = fmaf(dz, yv[k], s2[k]);
+              if (a.bs_store_masked) vals[k] = dz;     // what is stored IS the next BatchNorm backward's dz
+            }
+          }
+        }
+        const unsigned vo = pok ? (unsigned)((((ni * a.H + oy) * a.W + ox) * a.Cout + cbase) * 2) : OOB;
+#pragma unroll
+        for (int k0 = 0; k0 < C::LANE_C; k0 += 8) {
+          __builtin_amdgcn_raw_buffer_store_b128(v16_pack<bf16_t>(vals + k0), ry, pok ? vo + k0 * 2 : OOB, 0, 0);
           ++cnt;
         }
       }
@@ -457,30 +552,60 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void conv_ring_kernel(R
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < WPX; ++q) s += sl[(q * 2 + which) * NB + cl];
-      if (n0 + cl < a.Cout)
-        atomicAdd(a.stats + ((size_t)(wg_p & (HR_BN_COPIES - 1)) * 2 + which) * a.Cout + n0 + cl, s);
+      if (n0 + cl < a.Cout) {
+        if constexpr (BS) a.stats[((size_t)wg_p * 2 + which) * a.Cout + n0 + cl] = s;       // one row per pixel walk
+        else atomicAdd(a.stats + ((size_t)(wg_p & (HR_BN_COPIES - 1)) * 2 + which) * a.Cout + n0 + cl, s);
+      }
     }
   }
 }
 
 struct RingPlan {
   int id;        // 0 = not served
-  int th, tw, nb, per_cu;
+  int th, tw, ti, nb, per_cu;   // per_cu: workgroups per CU the grid aims at (0: one tile per workgroup)
 };
 
-// which instantiation serves a layer (0: none). Shapes: the four branch widths of pose_hrnet w32 / w48.
-inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout) {
+// which instantiation serves a layer (0: none). Shapes: the branch widths of pose_hrnet (w32: 32 / 64 / 128 / 256).
+// The narrow, HBM-bound layers keep their weights resident and walk several tiles; the wide layers (small maps,
+// large weight matrices) get FEW fat workgroups - 64 output channels x a whole image (or several 8x8 images), the
+// weight slices streamed once per workgroup - because what they move is mostly weights: 256 ch @ 8x8 as 512
+// workgroups of (one image, 32 channels) pulls 75 MB of weights through the CUs' load paths for a 6 MB layer.
+inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
   (void)N;
-  if (Cin % 32 != 0 || Cout % 16 != 0 || Cin > HR_RING_MAXC) return RingPlan{0, 0, 0, 0, 0};
-  if (Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 32, 2};
-  if (Cin == 64 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 32, 2};
-  return RingPlan{0, 0, 0, 0, 0};
+  static const int wide8 = getenv("HRNET_RING_TI8") ? atoi(getenv("HRNET_RING_TI8")) : 4;   // (measurement: 2 or 4)
+  static const int wide16 = getenv("HRNET_RING_TI16") ? atoi(getenv("HRNET_RING_TI16")) : 1;   // (measurement: 1 or 2)
+  if (Cin % 32 != 0 || Cout % 16 != 0 || Cin > HR_RING_MAXC) return RingPlan{0, 0, 0, 0, 0, 0};
+  if (!bs && Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 1, 32, 2};
+  if (!bs && Cin == 64 && Cout >= 32 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 1, 32, 2};
+  if (Cin >= 96 && Cout >= 64 && H == 8 && W == 8) return wide8 == 2 ? RingPlan{5, 8, 8, 2, 64, 0} : RingPlan{4, 8, 8, 4, 64, 0};
+  if (Cin >= 96 && Cout >= 64 && H == 16 && W == 16 && wide16 == 2) return RingPlan{6, 16, 16, 2, 64, 0};
+  if (Cin >= 96 && Cout >= 64 && H >= 16 && W >= 16) return RingPlan{3, 16, 16, 1, 64, 0};
+  return RingPlan{0, 0, 0, 0, 0, 0};
 }
 
 int g_ring_enabled = -1;
 #ifdef HR_RING_STAMP
 unsigned long long* g_ring_stamp = nullptr;
 #endif
+
+inline void ring_grid(const RingPlan& p, int N, int H, int W, int Cout, int& tiles_y, int& tiles_x, int& total, int& tpw,
+                      int& gx, int& gy) {
+  tiles_y = (H + p.th - 1) / p.th; tiles_x = (W + p.tw - 1) / p.tw;
+  total = ((N + p.ti - 1) / p.ti) * tiles_y * tiles_x;
+  gy = (Cout + p.nb - 1) / p.nb;
+  tpw = 1;
+  if (p.per_cu > 0) {
+    // (measurement overrides: workgroups of the two narrow instantiations)
+    static const int wgs1 = getenv("HRNET_RING_WGS1") ? atoi(getenv("HRNET_RING_WGS1")) : 0;
+    static const int wgs2 = getenv("HRNET_RING_WGS2") ? atoi(getenv("HRNET_RING_WGS2")) : 0;
+    int target = 256 * p.per_cu;
+    if (p.id == 1 && wgs1 > 0) target = wgs1;
+    if (p.id == 2 && wgs2 > 0) target = wgs2;
+    tpw = (total * gy + target - 1) / target;
+    if (tpw < 1) tpw = 1;
+  }
+  gx = (total + tpw - 1) / tpw;
+}
 
 }  // namespace
 
@@ -503,41 +628,49 @@ int hr_conv_ring_enabled() {
 }
 
 extern "C" int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout) {
-  return hr_conv_ring_enabled() ? hr_conv_ring_supported(dtype, N, H, W, Cin, Cout) : 0;
+  return hr_conv_ring_enabled() ? hr_conv_ring_supported(dtype, N, H, W, Cin, Cout, 0) : 0;
 }
 
-int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout) {
+int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout, int bs) {
   if (dtype != HR_BF16) return 0;
   if ((double)N * H * W * (Cin > Cout ? Cin : Cout) * 2.0 >= 2147483648.0) return 0;   // 32-bit buffer offsets
-  return ring_plan(N, H, W, Cin, Cout).id;
+  return ring_plan(N, H, W, Cin, Cout, bs != 0).id;
 }
 
-int hr_conv_ring_name(int id, char* buf, int buflen) {
-  static const char* names[] = {"", "conv_ring_kernel<16, 16, 32, 4, 4, 3, 1>", "conv_ring_kernel<8, 16, 32, 4, 4, 3, 2>"};
-  return snprintf(buf, buflen, "%s", id >= 1 && id <= 2 ? names[id] : "");
+int hr_conv_ring_rows(int N, int H, int W, int Cin, int Cout) {
+  const RingPlan p = ring_plan(N, H, W, Cin, Cout, true);
+  if (!p.id) return 0;
+  int ty, tx, total, tpw, gx, gy;
+  ring_grid(p, N, H, W, Cout, ty, tx, total, tpw, gx, gy);
+  return gx;
+}
+
+int hr_conv_ring_name(int id, int bs, char* buf, int buflen) {
+  static const char* names[] = {"", "16, 16, 1, 32, 4, 4, 3, 1", "8, 16, 1, 32, 4, 4, 3, 2", "16, 16, 1, 64, 8, 4, 2, 0",
+                                "8, 8, 4, 64, 8, 4, 2, 0", "8, 8, 2, 64, 8, 4, 2, 0", "16, 16, 2, 64, 8, 4, 2, 0"};
+  if (id < 1 || id > 6) return snprintf(buf, buflen, "%s", "");
+  return snprintf(buf, buflen, "conv_ring_kernel<%s, %s>", names[id], bs ? "true" : "false");
 }
 
 int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
-  const RingPlan p = ring_plan(c.N, c.H, c.W, c.Cin, c.Cout);
+  const bool bs = c.bs_y != nullptr || c.accumulate;
+  const RingPlan p = ring_plan(c.N, c.H, c.W, c.Cin, c.Cout, bs);
   HR_REQUIRE(p.id != 0, "conv_ring: shape not served (Cin %d Cout %d %dx%d)", c.Cin, c.Cout, c.H, c.W);
   HR_REQUIRE(c.x && c.w && c.y, "conv_ring: null pointer");
   HR_REQUIRE(!c.in_sums || c.in_gb, "conv_ring: batch sums need gamma/beta");
   HR_REQUIRE((c.in_scale == nullptr) == (c.in_shift == nullptr), "conv_ring: scale/shift must come together");
   HR_REQUIRE(!(c.in_sums && c.in_scale), "conv_ring: batch sums OR scale/shift");
+  HR_REQUIRE(!bs || (!c.in_sums && !c.in_scale && !c.in_relu), "conv_ring: an input-gradient launch reads a raw input");
+  HR_REQUIRE(!c.bs_y || c.stats, "conv_ring: backward statistics need a rows buffer");
+  HR_REQUIRE((c.bs_scale == nullptr) == (c.bs_shift == nullptr), "conv_ring: mask scale/shift must come together");
   RingArgs a;
   a.x = (const char*)c.x; a.w = (const char*)c.w; a.y = (char*)c.y;
   a.in_sums = c.in_sums; a.in_gb = c.in_gb; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.stats = c.stats; a.in_inv_count = c.in_inv_count; a.in_eps = c.in_eps;
+  a.bs_y = (const char*)c.bs_y; a.bs_mask = (const char*)c.bs_mask; a.bs_scale = c.bs_scale; a.bs_shift = c.bs_shift;
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
-  a.tiles_y = (c.H + p.th - 1) / p.th; a.tiles_x = (c.W + p.tw - 1) / p.tw;
-  a.total_tiles = c.N * a.tiles_y * a.tiles_x;
-  a.gy = (c.Cout + p.nb - 1) / p.nb;
-  const int target = 256 * p.per_cu;
-  int tpw = (a.total_tiles * a.gy + target - 1) / target;
-  if (tpw < 1) tpw = 1;
-  a.tpw = tpw;
-  a.gx = (a.total_tiles + tpw - 1) / tpw;
-  a.in_relu = c.in_relu;
+  ring_grid(p, c.N, c.H, c.W, c.Cout, a.tiles_y, a.tiles_x, a.total_tiles, a.tpw, a.gx, a.gy);
+  a.in_relu = c.in_relu; a.accumulate = c.accumulate; a.bs_store_masked = c.bs_store_masked;
   a.x_bytes = (unsigned)((size_t)c.N * c.H * c.W * c.Cin * 2);
   a.y_bytes = (unsigned)((size_t)c.N * c.H * c.W * c.Cout * 2);
   a.w_bytes = (unsigned)((size_t)c.Cout * 9 * c.Cin * 2);
@@ -545,10 +678,24 @@ int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
   a.stamp = g_ring_stamp;
 #endif
   const unsigned grid = (unsigned)((a.gx * a.gy + 7) / 8 * 8);
-  switch (p.id) {
-    case 1: hipLaunchKernelGGL((conv_ring_kernel<16, 16, 32, 4, 4, 3, 1>), dim3(grid), dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_ring_kernel<8, 16, 32, 4, 4, 3, 2>), dim3(grid), dim3(256), 0, s, a); break;
-    default: break;
+#define RING(BS_, NW_, ...) hipLaunchKernelGGL((conv_ring_kernel<__VA_ARGS__, BS_>), dim3(grid), dim3(NW_ * 64), 0, s, a)
+  if (!bs) {
+    switch (p.id) {
+      case 1: RING(false, 4, 16, 16, 1, 32, 4, 4, 3, 1); break;
+      case 2: RING(false, 4, 8, 16, 1, 32, 4, 4, 3, 2); break;
+      case 3: RING(false, 8, 16, 16, 1, 64, 8, 4, 2, 0); break;
+      case 4: RING(false, 8, 8, 8, 4, 64, 8, 4, 2, 0); break;
+      case 6: RING(false, 8, 16, 16, 2, 64, 8, 4, 2, 0); break;
+      default: RING(false, 8, 8, 8, 2, 64, 8, 4, 2, 0); break;
+    }
+  } else {
+    switch (p.id) {
+      case 3: RING(true, 8, 16, 16, 1, 64, 8, 4, 2, 0); break;
+      case 4: RING(true, 8, 8, 8, 4, 64, 8, 4, 2, 0); break;
+      case 6: RING(true, 8, 16, 16, 2, 64, 8, 4, 2, 0); break;
+      default: RING(true, 8, 8, 8, 2, 64, 8, 4, 2, 0); break;
+    }
   }
+#undef RING
   return hr_check_launch("conv_ring");
 }

@@ -30,7 +30,10 @@ struct WgradArgs {
   int N, H, W, Cin, Ho, Wo, Cout;
   int tiles_y, tiles_x, total_tiles;
   int in_relu;
-  int atomic;      // every split adds into slab 0 with float atomics (no reduce over splits afterwards)
+  // atomic = 1: `slabs` IS the OIHW f32 gradient [Cout_real][Cin_real][ks][ks]; every workgroup ADDS its tile into it
+  // with float atomics (no slabs, no reduce launch). 3x3: the tile goes through LDS so that a wave instruction adds
+  // 64 consecutive floats of one output channel's [ci][tap] run
+  int atomic, Cout_real, Cin_real;
 };
 
 // lane's KSTEP-deep operand fragment for 16 channels starting at byte offset `choff` of each
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   constexpr int DVPP = BCO / VEC;            // 16-byte vectors per dY pixel
   static_assert(WCO * WN == 4 && FCO % WCO == 0, "wave grid");
   static_assert(BM % KSTEP == 0 && TW % VEC == 0, "pixel groups stay inside a tile row");
-  __shared__ __attribute__((aligned(16))) char lds[XBYTES + BM * DYB];
+  constexpr int LDSTOT = (XBYTES + BM * DYB) > 16 * KC * TAPS * 4 ? (XBYTES + BM * DYB) : 16 * KC * TAPS * 4;
+  __shared__ __attribute__((aligned(16))) char lds[LDSTOT];
   char* xl = lds;
   char* dl = lds + XBYTES;
 
@@ -210,10 +214,62 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     __syncthreads();
   }
 
+  if (a.atomic) {
+    if constexpr (TAPS == 1) {
+      // [co][ci]: the 16 lanes of an accumulator row are 16 consecutive floats
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        const int fr = wn + WN * j;
+        if (fr < NFR) {
+          const int ci = c0 + (fr % FCI) * 16 + li;
+#pragma unroll
+          for (int f = 0; f < FCOW; ++f) {
+            const int co = co0 + (wco * FCOW + f) * 16 + lg * 4;
+            const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < a.Cout_real && ci < a.Cin_real) atomicAdd(a.slabs + (size_t)(co + r) * a.Cin_real + ci, v4[r]);
+          }
+        }
+      }
+    } else {
+      // through LDS as [co][ci][tap] (the loop ended on a barrier: the images are free), 16 output channels at a time
+      constexpr int HCO = 16, NH = BCO / HCO;
+      static_assert(HCO * KC * TAPS * 4 <= LDSTOT, "weight-gradient tile does not fit the LDS images");
+      float* tl = (float*)lds;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+          const int fr = wn + WN * j;
+          if (fr < NFR) {
+            const int t = fr / FCI, cil = (fr % FCI) * 16 + li;
+#pragma unroll
+            for (int f = 0; f < FCOW; ++f) {
+              const int col = (wco * FCOW + f) * 16 + lg * 4 - h * HCO;
+              const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
+              if (col >= 0 && col < HCO) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tl[((col + r) * KC + cil) * TAPS + t] = v4[r];
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const int nci = min(KC, a.Cin_real - c0);      // real input channels of this block (<= 0: nothing to add)
+        for (int idx = tid; idx < HCO * KC * TAPS; idx += 256) {
+          const int col = idx / (KC * TAPS), rem = idx - col * (KC * TAPS);
+          const int co = co0 + h * HCO + col;
+          if (co < a.Cout_real && rem < nci * TAPS)
+            atomicAdd(a.slabs + ((size_t)co * a.Cin_real + c0) * TAPS + rem, tl[idx]);
+        }
+        if (h + 1 < NH) __syncthreads();
+      }
+    }
+    return;
+  }
   // slab[split][co][tap][ci]; D layout: col (lane&15) = ci, row 4*(lane>>4)+r = co
-  // (atomic form: one accumulator image shared by the splits; a wave instruction adds 4 rows x 16 contiguous
-  // floats = four 64-byte segments, the request size of the memory-side atomic units)
-  float* slab = a.slabs + (a.atomic ? (size_t)0 : (size_t)blockIdx.x * a.Cout * TAPS * a.Cin);
+  float* slab = a.slabs + (size_t)blockIdx.x * a.Cout * TAPS * a.Cin;
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int fr = wn + WN * j;
@@ -225,10 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < a.Cout && ci < a.Cin) {
-            float* dst = slab + ((size_t)(co + r) * TAPS + t) * a.Cin + ci;
-            if (a.atomic) atomicAdd(dst, v4[r]); else *dst = v4[r];
-          }
+          if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * TAPS + t) * a.Cin + ci] = v4[r];
       }
     }
   }
@@ -343,7 +396,9 @@ int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   a.tiles_x = (Wo + c.tw - 1) / c.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.in_relu = op.i[10];
-  a.atomic = op.i[12];
+  a.atomic = op.i[12]; a.Cout_real = op.i[13]; a.Cin_real = op.i[14];
+  HR_REQUIRE(!a.atomic || (a.Cout_real >= 1 && a.Cout_real <= Cout && a.Cin_real >= 1 && a.Cin_real <= Cin),
+             "wgrad: the atomic form needs the gradient's real channel counts (%d, %d)", a.Cout_real, a.Cin_real);
   dim3 grid((unsigned)nsplit, (unsigned)((Cout + c.bco - 1) / c.bco), (unsigned)((Cin + c.kc - 1) / c.kc));
   if (dtype == HR_F32) return launch_wg<float, 16, 32>(a, c, ks, stride, grid, s);
   return launch_wg<bf16_t, 32, 64>(a, c, ks, stride, grid, s);

@@ -258,19 +258,6 @@ class Plan(object):
         self.keep.append(t)
         return t
 
-    def _slabs(self, nsplit, per_slab):
-        """weight-gradient partials of one layer: `nsplit` slabs, or (atomic mode) one accumulator image out of
-        the arena the backward pass zeroes; returns (tensor, number of slabs the reduce entry sums)"""
-        if self._acc_arena is not None:
-            t = self._acc_arena[self._acc_off:self._acc_off + per_slab]
-            assert t.numel() == per_slab, 'accumulator arena too small'
-            self._acc_off += per_slab
-            self.slab_bytes += per_slab * 4
-            return t, 1
-        t = self._f32(nsplit * per_slab)
-        self.slab_bytes += t.numel() * 4
-        return t, nsplit
-
     def _scratch(self, prog, idx, slot, kind):
         self.pending.append((prog, idx, slot, kind))
 
@@ -294,8 +281,11 @@ class Plan(object):
         sums_in = self.bn_sums and xin.bn is not None       # the input's BatchNorm from its batch sums, on the fly
         m_in = xin.bn.mod if xin.bn is not None else None
         ps = self._pending_sum
+        # (the wide layers' fat LDS-ring launches take one input tensor: their residual sums stay separate launches)
+        fat = (ks == 3 and stride == 1 and cin >= 96 and (self.bn_sums or not want_stats)
+               and C.call('hrnet_conv_ring_supported', self.dtid, x.N, x.H, x.W, cin, crec.Cout_pad) >= 3)
         if (ps is not None and ps['out'] is x and xin.bn is None and not xin.relu and stride == 1 and not crec.stem
-                and bias is None and ps['lane'] == self.fwd.lane):
+                and bias is None and ps['lane'] == self.fwd.lane and not fat):
             # the residual sum that produced x has not been emitted: this conv forms it in its prologue and writes
             # it out on the side (hrnet_conv2d_sum) - one launch and one tensor read less per block
             self._pending_sum = None
@@ -645,20 +635,14 @@ class Plan(object):
         self.gout_op = self.bwd.add(C.OP_NCHW_TO_NHWC, ints=(self.dtid, oa.N, oa.H, oa.W, oa.C, self.nj),
                                     ptrs=(None, C.ptr(oa.g)))
         oa.ginit = True
-        # Weight gradients by float atomics (default): every workgroup of a weight-gradient / fused backward launch
-        # adds its tile into ONE f32 accumulator image per layer ([Cout][tap][Cin], zeroed by one fill at the start
-        # of the pass) instead of writing a slab per split that a reduce launch reads back - the table launches
-        # that remain only transpose the accumulators into the OIHW gradients (1.94 GB of slabs written and read
-        # back per step before). HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps the slabs and their ordered sums.
+        # Weight gradients by float atomics (default): every workgroup of a weight-gradient / fused backward launch ADDS
+        # its tile straight into the OIHW f32 gradient (3x3 tiles go through LDS so that a wave instruction covers 64
+        # consecutive floats) instead of writing a slab per split that a reduce launch reads back: no slabs (1.94 GB
+        # written and read back per step before), no reduce launches, and nothing left to do when the last
+        # weight-gradient launch ends. HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps slabs + ordered sums.
         self.wgrad_atomic = (os.environ.get('HRNET_BATCH_WRED', '1') != '0'
                              and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
                              and os.environ.get('HRNET_WGRAD_ATOMIC', '1') != '0')
-        self._acc_arena, self._acc_off = None, 0
-        if self.wgrad_atomic:
-            total = sum(c.Cout_pad * (1 if c.stem else c.ks) ** 2 * c.Cin_pad for c in net.convs.values())
-            self._acc_arena = self._f32(total)
-            nbytes = total * 4
-            self.bwd.add(C.OP_FILL, ints=(nbytes & 0xffffffff, nbytes >> 32), ptrs=(C.ptr(self._acc_arena),))
         relu_of = {}   # act -> relu flag its consumers apply (uniform per act in this network)
         for e in self.tape:
             if e[0] == 'conv':
@@ -845,14 +829,31 @@ class Plan(object):
                     nsplit = max(1, floor_, nsplit // max(div, 1))
                     while nsplit > 1 and tiles % nsplit != 0:
                         nsplit -= 1
+                # (the stem's weights are a flattened 3x3x3 kernel over im2col columns: its slab layout stays)
+                direct = self.batch_wred and self.wgrad_atomic and not crec.stem
                 wints = (self.dtid, x.N, x.H, x.W, x.C, y.H, y.W, y.C, ks, stride, 1 if xin.relu else 0, nsplit,
-                         1 if (self.batch_wred and self.wgrad_atomic) else 0)
+                         1 if direct else 0, crec.Cout, crec.Cin)
                 wptrs = [C.ptr(x.t), C.ptr(y.g), C.ptr(xin.bn.scale) if xin.bn else None,
                          C.ptr(xin.bn.shift) if xin.bn else None, None]
-                if self.batch_wred:
-                    slabs, nred = self._slabs(nsplit, y.C * ks * ks * x.C)
+                if direct:
+                    wptrs[4] = C.ptr(net.grad_of(w))
+                    if deferred:
+                        self._deferred.append((wints, wptrs, None, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
+                    elif self.offload_wgrad and lane == 0 and not in_region:
+                        l = 1 + self._offload_rr % max(1, self.nlanes - 1)
+                        self._offload_rr += 1
+                        self.bwd.sync(0, l)
+                        self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
+                        self._offload_lanes.add(l)
+                    else:
+                        self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
+                        if lane == 0:
+                            self._wred_bytes += crec.Cout * crec.Cin * crec.ks * crec.ks * 4
+                elif self.batch_wred:
+                    slabs = self._f32(nsplit * y.C * ks * ks * x.C)
+                    self.slab_bytes += slabs.numel() * 4
                     wptrs[4] = C.ptr(slabs)
-                    ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nred, Cout_pad=y.C, Cin_pad=x.C,
+                    ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C,
                                ks=crec.ks if crec.stem else ks, Cout=crec.Cout, Cin=crec.Cin, kflat=1 if crec.stem else 0,
                                accumulate=1)
                     if deferred:
@@ -907,7 +908,7 @@ class Plan(object):
                             ptrs[8] = C.ptr(x.t) if relu_out else None
                     store_masked = 0
                     if target is not None:
-                        nrows = C.call('hrnet_conv_tiles_bwdstats', x.N, x.H, x.W, x.C, ks, stride)
+                        nrows = C.call('hrnet_conv_rows_bwdstats', self.dtid, x.N, x.H, x.W, y.C, x.C, ks, stride)
                         rows = self._f32(nrows * 2 * x.C)
                         ptrs[6] = C.ptr(rows)
                         target.bwd_rows = (rows, nrows)
@@ -1087,11 +1088,13 @@ class Plan(object):
             kind = C.OP_BWD_PW
             if rows_for is not None and not C.call('hrnet_bwd_pw_rows_supported', self.dtid, x.C, y.C):
                 rows_for = None               # (the BatchNorm backward behind it runs its own reduction pass)
-        atomic = 1 if (self.batch_wred and self.wgrad_atomic) else 0
+        w = crec.mod.weight
+        atomic = 1 if (self.batch_wred and self.wgrad_atomic
+                       and (ks == 3 or (crec.Cout == y.C and crec.Cin == x.C))) else 0
         if atomic:
-            slabs, nred = self._slabs(ns, y.C * ks * ks * x.C)
+            slabs = net.grad_of(w)               # the launch adds into the OIHW gradient itself
         else:
-            slabs, nred = self._f32(ns * y.C * ks * ks * x.C), ns
+            slabs = self._f32(ns * y.C * ks * ks * x.C)
             self.slab_bytes += slabs.numel() * 4
         rows = None
         if rows_for is not None:
@@ -1099,14 +1102,18 @@ class Plan(object):
             rows_for.bwd_rows = (rows, ns)
             self.n_fused_bwdstats += 1
         self.bwd.add(kind,
-                     ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0, atomic),
+                     ints=(self.dtid, x.N, x.H, x.W, x.C, y.C, 1 if xin.relu else 0, 1 if mask_out else 0, atomic,
+                           crec.Cout, crec.Cin),
                      ptrs=(dz, C.ptr(y.t), None if ref is not None else C.ptr(y.bn.coef), C.ptr(x.t),
                            C.ptr(xin.bn.scale) if xin.bn else None, C.ptr(xin.bn.shift) if xin.bn else None,
                            C.ptr(crec.wd), dx, addend, C.ptr(rows),
                            C.ptr(rows_for.t) if rows_for is not None else None, C.ptr(slabs),
                            ctypes.addressof(ref) if ref is not None else None))
-        w = crec.mod.weight
-        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=nred, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
+        if atomic:
+            if lane == 0:
+                self._wred_bytes += crec.Cout * crec.Cin * ks * ks * 4
+            return
+        ent = dict(slabs=C.ptr(slabs), grad=C.ptr(net.grad_of(w)), nsplit=ns, Cout_pad=y.C, Cin_pad=x.C, ks=ks,
                    Cout=crec.Cout, Cin=crec.Cin, kflat=0, accumulate=1)
         if self.batch_wred:
             self._wred.setdefault(lane, []).append(ent)
@@ -1220,7 +1227,8 @@ class Plan(object):
             l = min(side, key=lambda q: load[q])
             load[l] += cost
             self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
-            self._wred.setdefault(l, []).append(ent)
+            if ent is not None:
+                self._wred.setdefault(l, []).append(ent)
         self._deferred_lanes = side
         self.n_deferred_wgrads = len(self._deferred)
         self._deferred = []

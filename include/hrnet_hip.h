@@ -43,9 +43,10 @@ enum {
 enum {
   HR_OP_CONV = 1,          /* conv / dgrad (implicit GEMM, MFMA); a backward-statistics op may set i[14] = 1: the
                               stored gradient is dz = v * [mask > 0] (what the fused backward launches expect) */
-  HR_OP_WGRAD = 2,         /* weight gradient partial slabs; i[12] = 1: every split ADDS its tile into slab 0 with float
-                              atomics (the caller zeroes it; no sum over splits afterwards). HR_OP_BWD_FUSED / HR_OP_BWD_PW
-                              take the same switch in i[8] */
+  HR_OP_WGRAD = 2,         /* weight gradient partial slabs; i[12] = 1: p[4] is the OIHW f32 gradient itself
+                              ([i[13] = real Cout][i[14] = real Cin][ks][ks]) and every workgroup ADDS its tile into it with
+                              float atomics - no slabs, no reduce launch, not bit-reproducible. HR_OP_BWD_FUSED / HR_OP_BWD_PW
+                              take the same switch in i[8] (gradient in p[11], real Cout / Cin in i[9] / i[10]) */
   HR_OP_WGRAD_REDUCE = 3,  /* slabs -> OIHW f32 gradient */
   HR_OP_BN_FINALIZE = 4,   /* stat partials -> scale/shift (+ running stats) */
   HR_OP_SUM_TERMS = 5,     /* out = relu(sum_t relu_t(affine_t(up_t(src_t)))) */
@@ -155,6 +156,9 @@ int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, floa
  */
 int hrnet_conv_ring_enable(int on);
 int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout);
+/* statistics rows hrnet_conv2d_bwdstats leaves for a launch of this shape (hrnet_conv_tiles_bwdstats() for the
+ * tile-walking body; the pixel walks of the LDS-ring grid where that serves the launch) */
+int hrnet_conv_rows_bwdstats(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride);
 
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,

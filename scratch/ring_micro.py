@@ -59,7 +59,63 @@ def case(N, H, W, Cin, Cout, mode, timing=True):
     return same
 
 
+def case_bs(N, H, W, Cc, masked, accumulate, timing=True):
+    """input gradient with backward statistics (hrnet_conv2d_bwdstats): ring vs the tile-walking body"""
+    torch.manual_seed(2)
+    dy = (torch.randn(N, H, W, Cc, device='cuda')).to(dt)
+    w = torch.randn(Cc, Cc, 3, 3) * 0.05
+    wp, cop, cip = hh.pack_weights(w, dt, mode=1)
+    bs_y = torch.randn(N, H, W, Cc, device='cuda').to(dt)
+    bs_m = torch.randn(N, H, W, Cc, device='cuda').to(dt) if masked == 'mask' else None
+    bsc = (torch.rand(Cc, device='cuda') + 0.5) if masked == 'affine' else None
+    bsh = (torch.rand(Cc, device='cuda') - 0.5) if masked == 'affine' else None
+    y_init = torch.randn(N, H, W, Cc, device='cuda').to(dt)
+    res = []
+    def run(ring, y, rows):
+        C.call('hrnet_conv_ring_enable', ring)
+        C.call('hrnet_conv2d_bwdstats', 1, dy.data_ptr(), wp.data_ptr(), y.data_ptr(), rows.data_ptr(), bs_y.data_ptr(), C.ptr(bs_m), C.ptr(bsc), C.ptr(bsh),
+               N, H, W, Cc, H, W, Cc, 3, 1, 0, 1 if accumulate else 0, C.stream_ptr())
+    for ring in (0, 1):
+        C.call('hrnet_conv_ring_enable', ring)
+        nrows = C.call('hrnet_conv_rows_bwdstats', 1, N, H, W, Cc, Cc, 3, 1)
+        y = y_init.clone()
+        rows = torch.zeros(nrows, 2, Cc, device='cuda')
+        run(ring, y, rows)
+        torch.cuda.synchronize()
+        res.append((y, rows.double().sum(0), nrows))
+    (y0, r0, n0), (y1, r1, n1) = res
+    same = torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    nbad = (y0.view(torch.int16) != y1.view(torch.int16)).sum().item()
+    rrel = ((r0 - r1).abs().max() / r0.abs().max()).item()
+    msg = 'BS N%d %dx%d C%d %-6s acc%d: bitwise %s (%d differ) rows %d/%d rel %.2e' % (N, H, W, Cc, masked, accumulate, same, nbad, n0, n1, rrel)
+    if timing:
+        t = []
+        for ring in (0, 1):
+            C.call('hrnet_conv_ring_enable', ring)
+            nrows = C.call('hrnet_conv_rows_bwdstats', 1, N, H, W, Cc, Cc, 3, 1)
+            y = y_init.clone(); rows = torch.zeros(nrows, 2, Cc, device='cuda')
+            t.append(bench(lambda: run(ring, y, rows)))
+        msg += ' | old %.1f us  ring %.1f us' % (t[0], t[1])
+    print(msg, flush=True)
+    return same and rrel < 1e-4
+
+
 ok = True
+for mode in ('raw', 'bn'):
+    ok &= case(2, 16, 16, 128, 128, mode, False)
+    ok &= case(3, 20, 37, 128, 64, mode, False)
+    ok &= case(5, 8, 8, 256, 256, mode, False)
+    ok &= case(6, 8, 8, 128, 192, mode, False)
+    ok &= case(64, 16, 16, 128, 128, mode)
+    ok &= case(64, 8, 8, 256, 256, mode)
+for masked in ('none', 'affine', 'mask'):
+    for acc in (0, 1):
+        ok &= case_bs(3, 16, 16, 128, masked, acc, False)
+        ok &= case_bs(5, 8, 8, 256, masked, acc, False)
+ok &= case_bs(64, 16, 16, 128, 'mask', 1)
+ok &= case_bs(64, 8, 8, 256, 'mask', 1)
+ok &= case_bs(64, 16, 16, 128, 'affine', 0)
+ok &= case_bs(64, 8, 8, 256, 'affine', 0)
 for mode in ('raw', 'bn'):
     ok &= case(2, 16, 16, 32, 32, mode, False)
     ok &= case(3, 20, 37, 32, 32, mode, False)

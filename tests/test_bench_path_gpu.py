@@ -313,9 +313,15 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
     # the two dtypes must record the same op lists: the fp32 instantiation of the fused block backward serves
     # 32-channel layers only, so the fused run restricts both to those (the 64-channel bf16 instantiation is
     # covered by tests/test_bwd_fused_gpu.py and by test_fused_backward_matches_unfused_backward below)
+    # ... and the LDS-ring convolutions are bf16 only: the wide layers they serve keep their residual sums as separate
+    # launches, so one run records both dtypes without fused sums (ring kernels op by op), the other without the ring
+    # (hrnet_conv2d_sum op by op)
     if fused == 'unfused':
         monkeypatch.setenv('HRNET_FUSED_BWD', '0')
+        ring_prev = C.call('hrnet_conv_ring_enable', 0)      # (the library reads HRNET_CONV_RING once: use the switch)
     else:
+        ring_prev = C.call('hrnet_conv_ring_enable', 1)
+        monkeypatch.setenv('HRNET_FUSE_SUM', '0')
         monkeypatch.setenv('HRNET_FUSED_MAXC', '32')
         monkeypatch.setenv('HRNET_FUSED_PW', '0')     # (the pointwise fused backward of layer1 is bf16 only: tests/test_bwd_pw_gpu.py)
     m32, sd = _model('fp32', init='reference', salt=4)
