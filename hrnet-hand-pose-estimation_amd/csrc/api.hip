@@ -56,6 +56,7 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_BWD_PW: e = hr_launch_bwd_pw(op, s); break;
     case HR_OP_CONV_SUM: e = hr_launch_conv_sum(op, s); break;
     case HR_OP_BN_FINALIZE_TABLE: e = hr_launch_bn_finalize_table(op, s); break;
+    case HR_OP_EW_TABLE: e = hr_launch_ew_table(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");

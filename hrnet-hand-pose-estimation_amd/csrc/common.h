@@ -213,3 +213,4 @@ int hr_gemm_pw_supported(int dtype, int Cin, int Cout);
 int hr_gemm_pw(const void* x, const void* w, const float* bias, void* y, float* sums, long long pixels, int Cin,
                int Cout, hipStream_t s);
 int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s);
+int hr_launch_ew_table(const HrOp& op, hipStream_t s);

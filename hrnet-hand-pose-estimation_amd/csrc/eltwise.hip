@@ -225,13 +225,14 @@ __device__ __forceinline__ void compute_dz(const GradArgs& a, int n, int qy, int
   }
 }
 
+// (bid, nb: this block's index / the number of blocks of the job - a launch of its own, or a slice of a batched one)
 template <typename T>
-__global__ __launch_bounds__(256) void grad_term_kernel(GradArgs a) {
+__device__ __forceinline__ void grad_term_block(const GradArgs& a, int bid, int nb) {
   constexpr int VEC = TT<T>::VEC;
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.H * a.W * cv;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = (long long)bid * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)nb * blockDim.x) {
     const int v = (int)(idx % cv);
     long long pix = idx / cv;
     const int qx = (int)(pix % a.W);
@@ -269,6 +270,11 @@ __global__ __launch_bounds__(256) void grad_term_kernel(GradArgs a) {
       *(V16*)d2 = v16_pack<T>(dz);
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grad_term_kernel(GradArgs a) {
+  grad_term_block<T>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The same for large tensors (several grid-stride steps per thread): a thread owns ONE channel vector
@@ -335,9 +341,8 @@ __global__ __launch_bounds__(256) void grad_term_rows_kernel(GradArgs a) {
 
 // partials[block][2][C]; block = rows x cv threads, each thread owns one channel vector
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
+__device__ __forceinline__ void bn_bwd_reduce_block(const GradArgs& a, int bid, int nb, float* red) {
   constexpr int VEC = TT<T>::VEC;
-  __shared__ float red[256 * 2 * VEC];
   const int cv = a.C / VEC;
   const int rows = 256 / cv;
   const int v = threadIdx.x % cv, row = threadIdx.x / cv;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
   for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
   const long long npix = (long long)a.N * a.H * a.W;
   if (row < rows) {
-    for (long long pix = (long long)blockIdx.x * rows + row; pix < npix; pix += (long long)gridDim.x * rows) {
+    for (long long pix = (long long)bid * rows + row; pix < npix; pix += (long long)nb * rows) {
       const int qx = (int)(pix % a.W);
       const long long r = pix / a.W;
       const int qy = (int)(r % a.H);
@@ -373,16 +378,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
     const int vv = ch / VEC, jj = ch % VEC;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[((r * cv + vv) * 2 + which) * VEC + jj];
-    a.partials[((size_t)blockIdx.x * 2 + which) * a.C + ch] = s;
+    a.partials[((size_t)bid * 2 + which) * a.C + ch] = s;
   }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
+  __shared__ float red[256 * 2 * TT<T>::VEC];
+  bn_bwd_reduce_block<T>(a, (int)blockIdx.x, (int)gridDim.x, red);
+}
+
+__device__ __forceinline__ void bn_bwd_finalize_block(
     const float* partials, int blocks, int C, float count, const float* gamma, const float* save_mean,
-    const float* save_invstd, float* dgamma, float* dbeta, float* coef, int accumulate) {
-  __shared__ double red[2][FIN_LANES][32];
+    const float* save_invstd, float* dgamma, float* dbeta, float* coef, int accumulate, int bid,
+    double (*red)[FIN_LANES][32]) {
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = bid * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
   partial_sums(partials, blocks, C, c, tl, cl, red, s1, s2);
   if (tl == 0 && c < C) {
@@ -404,6 +415,68 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     coef[C + c] = (float)B;
     coef[2 * C + c] = (float)Cc;
   }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+    const float* partials, int blocks, int C, float count, const float* gamma, const float* save_mean,
+    const float* save_invstd, float* dgamma, float* dbeta, float* coef, int accumulate) {
+  __shared__ double red[2][FIN_LANES][32];
+  bn_bwd_finalize_block(partials, blocks, C, count, gamma, save_mean, save_invstd, dgamma, dbeta, coef, accumulate,
+                        (int)blockIdx.x, red);
+}
+
+// ---- batched launches (HR_OP_EW_TABLE): several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE jobs of
+// one kind as ONE launch. The table holds the jobs as HrOp records in device memory (slots as for the single ops;
+// i[16] = first block of the job, i[17] = its block count); a block finds its job by binary search. The module
+// fuse layers leave a dozen such jobs on tensors of a few MB per HighResolutionModule: as launches of their own
+// they are latency, not work. Same device code as the single launches: same values bit for bit.
+__device__ __forceinline__ const HrOp& ew_table_find(const HrOp* tab, int n, int& local) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].i[16] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  local = (int)blockIdx.x - tab[lo].i[16];
+  return tab[lo];
+}
+
+__device__ __forceinline__ GradArgs ew_grad_args(const HrOp& op, bool reduce) {
+  GradArgs a;
+  a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.sh = op.i[5]; a.inner_relu = op.i[6];
+  a.accumulate = reduce ? 0 : op.i[7];
+  a.accumulate2 = reduce ? 0 : op.i[8];
+  a.dst2 = reduce ? nullptr : (char*)op.p[7];
+  a.partials = reduce ? (float*)op.p[0] : nullptr;
+  a.dst = reduce ? nullptr : (char*)op.p[0];
+  a.coef = reduce ? nullptr : (const float*)op.p[6];
+  a.g = (const char*)op.p[1]; a.mask = (const char*)op.p[2]; a.y = (const char*)op.p[3];
+  a.scale = (const float*)op.p[4]; a.shift = (const float*)op.p[5];
+  return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grad_term_table_kernel(const HrOp* tab, int n) {
+  int local;
+  const HrOp& op = ew_table_find(tab, n, local);
+  const GradArgs a = ew_grad_args(op, false);
+  grad_term_block<T>(a, local, op.i[17]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_table_kernel(const HrOp* tab, int n) {
+  __shared__ float red[256 * 2 * TT<T>::VEC];
+  int local;
+  const HrOp& op = ew_table_find(tab, n, local);
+  const GradArgs a = ew_grad_args(op, true);
+  bn_bwd_reduce_block<T>(a, local, op.i[17], red);
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_table_kernel(const HrOp* tab, int n) {
+  __shared__ double red[2][FIN_LANES][32];
+  int local;
+  const HrOp& op = ew_table_find(tab, n, local);
+  bn_bwd_finalize_block((const float*)op.p[0], op.i[0], op.i[1], op.f[0], (const float*)op.p[1], (const float*)op.p[2],
+                        (const float*)op.p[3], (float*)op.p[4], (float*)op.p[5], (float*)op.p[6], op.i[2], local, red);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1140,6 +1213,35 @@ int hr_launch_bn_bwd_reduce(const HrOp& op, hipStream_t s) {
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
   return hr_check_launch("bn_bwd_reduce");
+}
+
+// HR_OP_EW_TABLE: p[0] = device table of HrOp jobs, i[0] = jobs, i[1] = total blocks, i[2] = kind of the jobs
+// (HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE), i[3] = dtype
+extern "C" int hrnet_ew_table_blocks(int kind, int dtype, int N, int H, int W, int C) {
+  const int vec = dtype == HR_F32 ? 4 : 8;
+  if (kind == HR_OP_GRAD_TERM) return (int)ew_grid((long long)N * H * W * (C / vec));
+  if (kind == HR_OP_BN_BWD_REDUCE) return hrnet_reduce_blocks(N, H, W, C);
+  if (kind == HR_OP_BN_BWD_FINALIZE) return (C + 31) / 32;
+  return 0;
+}
+
+int hr_launch_ew_table(const HrOp& op, hipStream_t s) {
+  const int n = op.i[0], blocks = op.i[1], kind = op.i[2], dtype = op.i[3];
+  HR_REQUIRE(op.p[0] && n >= 1 && blocks >= 1, "ew_table: args");
+  HR_REQUIRE(dtype == HR_F32 || dtype == HR_BF16, "ew_table: dtype %d", dtype);
+  const HrOp* tab = (const HrOp*)op.p[0];
+  if (kind == HR_OP_GRAD_TERM) {
+    if (dtype == HR_F32) hipLaunchKernelGGL(grad_term_table_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+    else hipLaunchKernelGGL(grad_term_table_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+  } else if (kind == HR_OP_BN_BWD_REDUCE) {
+    if (dtype == HR_F32) hipLaunchKernelGGL(bn_bwd_reduce_table_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+    else hipLaunchKernelGGL(bn_bwd_reduce_table_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+  } else if (kind == HR_OP_BN_BWD_FINALIZE) {
+    hipLaunchKernelGGL(bn_bwd_finalize_table_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, tab, n);
+  } else {
+    HR_REQUIRE(false, "ew_table: kind %d cannot be batched", kind);
+  }
+  return hr_check_launch("ew_table");
 }
 
 int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s) {

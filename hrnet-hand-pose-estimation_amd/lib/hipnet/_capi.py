@@ -25,6 +25,7 @@ class HrOp(ctypes.Structure):
 OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FUSED, OP_BN_FINALIZE_TABLE = 17, 18, 19, 20, 21, 22
 OP_BWD_PW = 23
 OP_CONV_SUM = 24
+OP_EW_TABLE = 25
 LANE_SLOT = 18
 
 
@@ -77,6 +78,7 @@ _SIGS = {
     'hrnet_conv2d_sum': [_c_int] + [_c_vp] * 8 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_int] * 7 + [_c_vp],
     'hrnet_sum_terms_bnref': [_c_int, _c_vp] + [_c_int] * 5 + [_pp, _pp, _pp, _ip, _ip, _c_int, _c_int, ctypes.POINTER(ctypes.c_float), _c_float, _c_vp],
     'hrnet_conv_mode': [_c_int] * 7,
+    'hrnet_ew_table_blocks': [_c_int] * 6,
     'hrnet_conv_ring_enable': [_c_int],
     'hrnet_conv_ring_supported': [_c_int] * 6,
     'hrnet_conv_rows_bwdstats': [_c_int] * 8,
@@ -137,7 +139,7 @@ _SIGS = {
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])

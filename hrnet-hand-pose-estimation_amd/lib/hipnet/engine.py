@@ -576,7 +576,7 @@ class Plan(object):
         sum_lanes = side and fuse_lanes and os.environ.get('HRNET_SUM_LANES', '1') != '0'
         if sum_lanes:
             self.fwd.fork(side)
-            self._tape(('fork', side))
+            self._tape(('fork', side, 'sums'))
         outs = []
         for i in range(nb):
             if sum_lanes:
@@ -590,7 +590,7 @@ class Plan(object):
         self.fwd.lane = 0
         if sum_lanes:
             self.fwd.join(side)
-            self._tape(('join', side))
+            self._tape(('join', side, 'sums'))
         return outs
 
     # ---- backward recording ---------------------------------------------------------------
@@ -606,9 +606,16 @@ class Plan(object):
             # the dgrad conv that finished g_src already gathered (sum dz, sum dz*y) in its epilogue
             rows, blocks = y.bwd_rows
             assert sh == 0
-            self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
-                         ptrs=(C.ptr(rows), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
-                               C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
+            self._emit(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
+                       ptrs=(C.ptr(rows), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                             C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
+        elif self._batch is not None:
+            part = self._f32(blocks * 2 * y.C)          # (a job of a batched launch: partial rows of its own)
+            self._emit(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
+                       ptrs=(C.ptr(part), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
+            self._emit(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
+                       ptrs=(C.ptr(part), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                             C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
         else:
             i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
                              ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
@@ -624,9 +631,51 @@ class Plan(object):
             ints[8] = 1 if extra.ginit else 0
             ptrs[7] = C.ptr(extra.g)
             extra.ginit = True
-        self.bwd.add(C.OP_GRAD_TERM, ints=ints, ptrs=ptrs)
+        self._emit(C.OP_GRAD_TERM, ints=ints, ptrs=ptrs)
         y.bn_done = True
         y.ginit = True
+
+    # ---- batched element-wise jobs (the backward of a HighResolutionModule's fuse sums) ----
+    def _emit(self, kind, ints=(), floats=(), ptrs=()):
+        """an HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE op: its own launch, or - while a batch is
+        open - a job of the batched launch of its kind (HR_OP_EW_TABLE)"""
+        if self._batch is None:
+            return self.bwd.add(kind, ints=ints, floats=floats, ptrs=ptrs)
+        op = C.HrOp()
+        op.kind = kind
+        for k, v in enumerate(ints):
+            op.i[k] = int(v)
+        for k, v in enumerate(floats):
+            op.f[k] = float(v)
+        for k, v in enumerate(ptrs):
+            op.p[k] = v
+        self._batch[kind].append(op)
+        return None
+
+    def _flush_batch(self):
+        """the open batch as (at most) three launches on lane 0: every reduction, every finalize, every apply job"""
+        batch, self._batch = self._batch, None
+        if batch is None:
+            return
+        self.bwd.lane = 0
+        for kind in (C.OP_BN_BWD_REDUCE, C.OP_BN_BWD_FINALIZE, C.OP_GRAD_TERM):
+            jobs = batch[kind]
+            if not jobs:
+                continue
+            block = 0
+            for op in jobs:
+                if kind == C.OP_BN_BWD_FINALIZE:
+                    nb = C.call('hrnet_ew_table_blocks', kind, self.dtid, 1, 1, 1, op.i[1])
+                else:
+                    nb = C.call('hrnet_ew_table_blocks', kind, self.dtid, op.i[1], op.i[2], op.i[3], op.i[4])
+                op.i[16], op.i[17] = block, nb
+                block += nb
+            arr = (C.HrOp * len(jobs))(*jobs)
+            raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self.keep.append(table)
+            self.bwd.add(C.OP_EW_TABLE, ints=(len(jobs), block, kind, self.dtid), ptrs=(C.ptr(table),))
+            self.n_batched_jobs += len(jobs)
 
     def _build_backward(self):
         net = self.net
@@ -639,10 +688,15 @@ class Plan(object):
         # its tile straight into the OIHW f32 gradient (3x3 tiles go through LDS so that a wave instruction covers 64
         # consecutive floats) instead of writing a slab per split that a reduce launch reads back: no slabs (1.94 GB
         # written and read back per step before), no reduce launches, and nothing left to do when the last
-        # weight-gradient launch ends. HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps slabs + ordered sums.
+        # weight-gradient launch ends. HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps slabs + ordered sums
+        # (HRNET_WGRAD_ATOMIC=1 beside HRNET_DETERMINISTIC=1: ordered batch statistics, atomic weight gradients - tests).
+        det = os.environ.get('HRNET_DETERMINISTIC', '0') == '1'
         self.wgrad_atomic = (os.environ.get('HRNET_BATCH_WRED', '1') != '0'
-                             and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
-                             and os.environ.get('HRNET_WGRAD_ATOMIC', '1') != '0')
+                             and os.environ.get('HRNET_WGRAD_ATOMIC', '0' if det else '1') != '0')
+        # batched backward of the fuse sums (HR_OP_EW_TABLE; HRNET_BATCH_SUMBWD=0: one launch per pass and lane)
+        self.batch_sums = os.environ.get('HRNET_BATCH_SUMBWD', '1') != '0'
+        self._batch = None
+        self.n_batched_jobs = 0
         relu_of = {}   # act -> relu flag its consumers apply (uniform per act in this network)
         for e in self.tape:
             if e[0] == 'conv':
@@ -729,10 +783,21 @@ class Plan(object):
                 for l in sorted(self._wred):
                     self._flush_wred(l)
                 self.bwd.lane = 0
-                if e[0] == 'join':
+                if self.batch_sums and len(e) > 2 and e[2] == 'sums':
+                    # the backward of the module's fuse sums (a dozen reduce / finalize / apply passes over tensors of
+                    # a few MB, three or four per lane in a row) runs as three batched launches on lane 0 instead:
+                    # no fork / join around it
+                    if e[0] == 'join':
+                        self._batch = {C.OP_BN_BWD_REDUCE: [], C.OP_BN_BWD_FINALIZE: [], C.OP_GRAD_TERM: []}
+                    else:
+                        self._flush_batch()
+                elif e[0] == 'join':
                     self.bwd.fork(e[1])
                 else:
                     self.bwd.join(e[1])
+                if e[0] == 'join':
+                    pass
+                else:
                     if self.defer_wgrad and ti == first_fork:
                         self._emit_deferred_wgrads()
                     if self.wlane:
@@ -782,9 +847,9 @@ class Plan(object):
                     else:
                         # accumulate d(post-activation value); BN backward runs at the producer
                         assert sh == 0
-                        self.bwd.add(C.OP_GRAD_TERM,
-                                     ints=(self.dtid, a.N, a.H, a.W, a.C, 0, 0, 1 if a.ginit else 0),
-                                     ptrs=(C.ptr(a.g), C.ptr(out.g), mask, None, None, None, None))
+                        self._emit(C.OP_GRAD_TERM,
+                                   ints=(self.dtid, a.N, a.H, a.W, a.C, 0, 0, 1 if a.ginit else 0),
+                                   ptrs=(C.ptr(a.g), C.ptr(out.g), mask, None, None, None, None))
                         a.ginit = True
             elif e[0] == 'conv':
                 _, xin, crec, stride, y, bnrec = e

@@ -68,7 +68,11 @@ enum {
   HR_OP_BWD_FUSED = 21,    /* hrnet_conv3x3_bwd_fused */
   HR_OP_BN_FINALIZE_TABLE = 22, /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
   HR_OP_BWD_PW = 23,       /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
-  HR_OP_CONV_SUM = 24      /* hrnet_conv2d_sum */
+  HR_OP_CONV_SUM = 24,     /* hrnet_conv2d_sum */
+  HR_OP_EW_TABLE = 25      /* several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE jobs as ONE launch:
+                              p[0] = device array of HrOp jobs (slots as for the single op; i[16] = first block of the
+                              job, i[17] = its blocks: hrnet_ew_table_blocks()), i[0] = jobs, i[1] = total blocks,
+                              i[2] = kind of the jobs, i[3] = dtype */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -85,6 +89,8 @@ int hrnet_abi_version(void);
 
 /* Run `n` recorded ops in order on `stream` (one host call per forward / backward pass). */
 int hrnet_program_run(const HrOp* ops, int n, hr_stream_t stream);
+/* blocks of one job of a HR_OP_EW_TABLE launch (kind = the single op's kind; finalize: N = H = W = 1) */
+int hrnet_ew_table_blocks(int kind, int dtype, int N, int H, int W, int C);
 /* The same over several streams: op.i[HR_LANE_SLOT] selects streams[lane]; HR_OP_EVENT_RECORD /
  * HR_OP_STREAM_WAIT ops express the dependencies between lanes (independent branches of a
  * HighResolutionModule, weight-gradient work off the critical path). Events come from
