@@ -54,10 +54,19 @@ struct BwdArgs {
   // atomic = 1: `slabs` IS the OIHW f32 gradient [Cout_real][Cin_real][3][3]; the workgroups ADD their tiles into it
   // with float atomics, through LDS so that a wave instruction covers 64 consecutive floats (no slabs, no reduce)
   int atomic, Cout_real, Cin_real;
-  unsigned long long* stamp;   // measurement only (HRNET_FUSED_STAMP_PTR): 32 s_memtime stamps per workgroup
-  int ablate;   // measurement only (HRNET_FUSED_ABLATE): 1 skip input-gradient MFMAs, 2 skip weight-gradient MFMAs, 4 skip the
-                // epilogue's global traffic, 8 skip the tile loads (stage zeros)
+#ifdef HR_MEASURE
+  // measurement builds only (scratch/build_variant.py measure -DHR_MEASURE; never in the shipped library):
+  unsigned long long* stamp;   // HRNET_FUSED_STAMP_PTR: 32 s_memtime stamps per workgroup
+  int ablate;   // HRNET_FUSED_ABLATE: 1 skip input-gradient MFMAs, 2 skip weight-gradient MFMAs, 4 skip the epilogue's
+                // global traffic, 8 skip the tile loads (stage zeros)
+#endif
 };
+
+#ifdef HR_MEASURE
+#define HR_ABLATE(a, bit) (((a).ablate & (bit)) != 0)
+#else
+#define HR_ABLATE(a, bit) (false)
+#endif
 
 template <typename T>
 __device__ __forceinline__ V16 trl(const char* base, int r0, int rstep, int choff, int lane);
@@ -127,7 +136,11 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   if (split >= a.nsplit) return;
   const int c0 = cb * CB;
   int stamp_i = 0;
+#ifdef HR_MEASURE
 #define FSTAMP() do { if (a.stamp && tid == 0 && stamp_i < 32) a.stamp[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP() do { (void)stamp_i; } while (0)
+#endif
   FSTAMP();
 
   // ---- weights of this input-channel block: resident for the whole walk ----
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 
   int t = split;
   if (t < a.total_tiles) load_tile(t);
-  if (a.ablate & 8) { okg = oka = 0; }
+  if HR_ABLATE(a, 8) { okg = oka = 0; }
   FSTAMP();
   for (; t < a.total_tiles; t += a.nsplit) {
     FSTAMP();
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     FSTAMP();
     __syncthreads();
     FSTAMP();
-    const bool has_next = t + a.nsplit < a.total_tiles && !(a.ablate & 8);
+    const bool has_next = t + a.nsplit < a.total_tiles && !HR_ABLATE(a, 8);
     if (has_next) load_begin(t + a.nsplit);
     int n, ty, tx;
     tile_of(t, n, ty, tx);
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     for (int fp = 0; fp < FP; ++fp) {
       const int p = wave * PW + fp * 16 + li;
       const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
-      pok[fp] = ci_ok && oy < a.H && ox < a.W && !(a.ablate & 4);
+      pok[fp] = ci_ok && oy < a.H && ox < a.W && !HR_ABLATE(a, 4);
       poff[fp] = (oy * a.W + ox) * pixA + ci0 * ES;          // within image n
 #pragma unroll
       for (int q = 0; q < EV; ++q) {
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     for (int fc = 0; fc < 2; ++fc)
 #pragma unroll
       for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(a.ablate & 1))
+    if (!HR_ABLATE(a, 1))
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int tapb = ((tp / 3) * HALO + (tp % 3)) * GPIX;
@@ -716,8 +729,10 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
   a.nsplit = hrnet_bwd_fused_splits(dtype, N, H, W, Cin, Cout);
   a.in_relu = in_relu; a.mask_out = mask_out;
   a.atomic = atomic; a.Cout_real = Cout_real; a.Cin_real = Cin_real;
+#ifdef HR_MEASURE
   { static const char* sp = getenv("HRNET_FUSED_STAMP_PTR"); a.stamp = sp ? (unsigned long long*)strtoull(sp, nullptr, 16) : nullptr; }
   { static const int abl = getenv("HRNET_FUSED_ABLATE") ? atoi(getenv("HRNET_FUSED_ABLATE")) : 0; a.ablate = abl; }
+#endif
   const unsigned grid = (unsigned)((a.nsplit + 7) / 8 * 8 * a.ncb);
   hipStream_t s = (hipStream_t)stream;
 #define FUSED(T_, COP_, TH_, NW_, WCO_, WN_, Y_) \

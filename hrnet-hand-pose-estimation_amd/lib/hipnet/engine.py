@@ -424,8 +424,12 @@ class Plan(object):
         # finalize launch after each of the 306 convs. HRNET_DETERMINISTIC=1: per-workgroup rows + a finalize launch
         # per BatchNorm (bit-reproducible statistics).
         contiguous = all(b.mod.bias.data_ptr() == b.mod.weight.data_ptr() + 4 * b.C for b in self.bns.values())
+        # capacity of the on-the-fly coefficient tables: 768 channels in the conv prologues (HR_CONV_MAXC: the head's
+        # 480 / 720), 384 in hrnet_sum_terms (SUM_MAXC: the widest BatchNorm that reaches a sum is a branch width -
+        # the head's BatchNorm is read by a conv); wider nets fall back to per-BatchNorm finalize launches
+        sum_w = max([b.C for n, b in self.bns.items() if not n.startswith('last_layer')] or [0])
         self.bn_sums = (self.training and contiguous and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
-                        and max(b.C for b in self.bns.values()) <= 768)
+                        and max(b.C for b in self.bns.values()) <= 768 and sum_w <= 384)
         self.bn_finalize_list = []
         if self.bn_sums:
             total = sum(16 * b.C for b in self.bns.values())

@@ -123,6 +123,16 @@ class GradSync(object):
                 self.cuts.append(op_index)
                 self._ranges[op_index] = (off, hi)
                 hi = off
+        if getattr(plan, 'defer_wgrad', False) or getattr(plan, 'offload_wgrad', False):
+            # this plan was recorded for a single process (before init_process_group, or while the default group had
+            # one rank): its deferred / offloaded weight-gradient launches finish only when the program ends, so no
+            # range is final at a mark - exchange everything once, after the last op
+            import warnings
+            warnings.warn('GradSync: the backward program was recorded with deferred weight gradients (single-process '
+                          'plan); the gradient is exchanged in one all-reduce after the pass instead of in overlapped '
+                          'buckets. Build the model after torch.distributed.init_process_group for the overlapped form.')
+            self.cuts, self._ranges = [], {}
+            hi = total
         self._tail = (0, hi)
         self._end = len(plan.bwd)
         self._plan = plan

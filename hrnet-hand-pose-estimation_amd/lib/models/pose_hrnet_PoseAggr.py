@@ -28,6 +28,7 @@ state_dict(): the reference's keys in the reference's order - trainable_temp, ba
 offsets1..5, deform_conv1..5 (weight, bias).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -199,6 +200,52 @@ class PoseHighResolutionNet(_SoftmaxNet):
             agg = self._aggregate(logits.contiguous(), net, plan)
             heat = _SpatialSoftmax.apply(agg, self.trainable_temp)
         return heat, self.trainable_temp
+
+
+    def init_weights(self, pretrained=''):
+        """reference pose_hrnet_PoseAggr.py:647-730 ("PoseWarper initialization"): every conv N(0, 0.001) / bias 0 and
+        every BatchNorm (1, 0) - all FROZEN (requires_grad False); the deformable convs start as the identity (centre
+        tap of channel k -> k is 1) and train; optional checkpoint; then, with USE_WARPING_TRAIN, the offset-feature
+        chain trains again and the five dilated offset convs are zeroed (the warp starts as the identity) and train."""
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.weight.normal_(std=0.001)
+                    m.weight.requires_grad = False
+                    if m.bias is not None:
+                        m.bias.zero_()
+                        m.bias.requires_grad = False
+                elif isinstance(m, nn.BatchNorm2d):
+                    m.weight.fill_(1)
+                    m.bias.zero_()
+                    m.weight.requires_grad = False
+                    m.bias.requires_grad = False
+                elif isinstance(m, DeformConv) and self.flag:
+                    m.weight.zero_()
+                    kh, kw = m.weight.shape[2] // 2, m.weight.shape[3] // 2
+                    for k in range(m.weight.shape[0]):
+                        m.weight[k, k, kh, kw] = 1.0
+                    m.weight.requires_grad = True
+        if os.path.isfile(pretrained):
+            state = torch.load(pretrained, map_location='cpu')
+            keep = {k: v for k, v in state.items()
+                    if k.split('.')[0] in self.pretrained_layers or self.pretrained_layers[0] == '*'}
+            self.load_state_dict(keep, strict=False)
+        elif pretrained:
+            raise ValueError('{} does not exist!'.format(pretrained))
+        if self.use_warping_train and self.flag:
+            for m in self.offset_feats.modules():
+                if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                    m.weight.requires_grad = True
+                    if m.bias is not None:
+                        m.bias.requires_grad = True
+            with torch.no_grad():
+                for k in range(1, len(self.dilation_rates) + 1):
+                    oc = getattr(self, 'offsets{}'.format(k))
+                    oc.weight.zero_()
+                    oc.weight.requires_grad = True
+        self._tap_cache = {}
+        self.invalidate_weights()
 
 
 def get_pose_net(cfg, is_train, **kwargs):

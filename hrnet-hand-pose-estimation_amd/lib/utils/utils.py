@@ -37,7 +37,12 @@ def get_optimizer(cfg, model):
     name = cfg.TRAIN.OPTIMIZER.lower()
     params = [{'params': [p for p in model.parameters() if p.requires_grad], 'initial_lr': cfg.TRAIN.LR}]
     inner = model.module if hasattr(model, 'module') else model
-    if name == 'adam' and hasattr(inner, 'hip') and os.environ.get('HRNET_TORCH_OPTIM', '0') != '1':
+    # FlatAdam steps the whole flat parameter buffer from the flat gradient buffer: right only when every parameter
+    # trains through the recorded programs. A model with frozen parameters (pose_hrnet_PoseAggr freezes its backbone,
+    # reference pose_hrnet_PoseAggr.py:647-730, and its head's gradients arrive as autograd .grad tensors) gets the
+    # torch optimiser over the parameters that require gradients, as the reference builds it (utils.py:83).
+    frozen = any(not p.requires_grad for n, p in inner.named_parameters() if n != 'trainable_temp')
+    if name == 'adam' and hasattr(inner, 'hip') and not frozen and os.environ.get('HRNET_TORCH_OPTIM', '0') != '1':
         from hipnet.optim import FlatAdam
         return FlatAdam(inner, lr=cfg.TRAIN.LR, weight_decay=cfg.TRAIN.WD)
     if name == 'sgd':

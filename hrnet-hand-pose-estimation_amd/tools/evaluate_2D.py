@@ -18,7 +18,7 @@ import torch
 from config import cfg, update_config
 from core.evaluate2d import Eval2DAccumulator, load_checkpoint_state
 from dataset.build import make_dataloader
-from models import pose_hrnet, pose_hrnet_softmax  # noqa: F401
+from models import pose_hrnet, pose_hrnet_PoseAggr, pose_hrnet_softmax  # noqa: F401
 from utils.heatmap_decoding import get_final_preds
 
 

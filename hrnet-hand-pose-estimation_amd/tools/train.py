@@ -20,7 +20,7 @@ from config import cfg, update_config
 from core.function import train, validate
 from core.loss import HeatmapLoss, JointsMSELoss
 from dataset.build import make_dataloader
-from models import pose_hrnet, pose_hrnet_softmax  # noqa: F401  (dispatched by name below)
+from models import pose_hrnet, pose_hrnet_PoseAggr, pose_hrnet_softmax  # noqa: F401  (dispatched by name below)
 from utils.utils import create_logger, get_optimizer, save_checkpoint
 
 

@@ -121,6 +121,61 @@ def test_poseaggr_variant_module_surface():
     assert len(plain.state_dict()) == 1840 and not plain.flag
 
 
+def test_poseaggr_init_freezes_the_backbone_and_starts_as_the_identity_warp():
+    """reference lib/models/pose_hrnet_PoseAggr.py:647-730 (init_weights, "PoseWarper initialization"), read from the
+    source (the reference module cannot be imported here: its deformable-conv extension is CUDA-only): every conv /
+    BatchNorm frozen, the offset-feature chain re-enabled, offsets1..5 zero and trainable, deform_conv1..5 identity
+    centre taps and trainable; get_optimizer then builds a torch optimiser over the trainable parameters only"""
+    from config import get_cfg_defaults
+    from models import pose_hrnet_PoseAggr
+    from utils.utils import get_optimizer
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml'))
+    cfg.MODEL.INIT_WEIGHTS = True
+    cfg.MODEL.PRETRAINED = ''
+    cfg.MODEL.USE_WARPING_TRAIN = True
+    m = pose_hrnet_PoseAggr.get_pose_net(cfg, is_train=True)
+    named = dict(m.named_parameters())
+    head = ('offset_feats.', 'offsets', 'deform_conv')
+    for name, p in named.items():
+        if name == 'trainable_temp':
+            continue
+        if name.startswith(head):
+            # (a DeformConv built with bias=True keeps a trainable bias; reference modules/deform_conv.py:38-41)
+            assert p.requires_grad, name
+        else:
+            assert not p.requires_grad, name                      # the whole backbone, convs and BatchNorms
+    w = named['stage3.0.branches.1.0.conv1.weight']
+    assert abs(float(w.std()) - 1e-3) < 1e-4
+    assert float((named['offset_feats.3.bn1.weight'] - 1).abs().max()) == 0.0
+    for k in range(1, 6):
+        assert float(named['offsets{}.weight'.format(k)].abs().max()) == 0.0
+        dw = named['deform_conv{}.weight'.format(k)]
+        eye = torch.zeros_like(dw)
+        for c in range(dw.shape[0]):
+            eye[c, c, 1, 1] = 1.0
+        assert torch.equal(dw.detach(), eye)
+    opt = get_optimizer(cfg, m)
+    assert isinstance(opt, torch.optim.Optimizer) and type(opt).__module__.startswith('torch.optim')
+    ids = {id(p) for g in opt.param_groups for p in g['params']}
+    assert ids == {id(p) for p in m.parameters() if p.requires_grad}
+    # the plain model keeps the fused flat-buffer optimiser
+    from models import pose_hrnet
+    cfg2 = get_cfg_defaults()
+    cfg2.merge_from_file(YAML)
+    assert not any(not p.requires_grad for p in pose_hrnet.get_pose_net(cfg2, is_train=False).parameters())
+
+
+def test_tools_dispatch_every_model_family_by_name():
+    """tools/train.py:152 and tools/evaluate_2D.py:92 of the reference resolve eval(cfg.MODEL.NAME + '.get_pose_net'):
+    the three families this build has must be importable names in both tools"""
+    for tool in ('train.py', 'evaluate_2D.py'):
+        src = open(os.path.join(PKG, 'tools', tool)).read()
+        line = next(l for l in src.splitlines() if l.startswith('from models import'))
+        for name in ('pose_hrnet', 'pose_hrnet_softmax', 'pose_hrnet_PoseAggr'):
+            assert name in [t.strip() for t in line.split('import', 1)[1].split('#')[0].split(',')], (tool, name)
+
+
 def test_init_weights_follows_reference_distribution():
     from config import get_cfg_defaults
     from models import pose_hrnet
@@ -212,6 +267,22 @@ def _gradsync_worker(rank, world, port, q):
     net.flat_g.fill_(float(rank + 1))
     sync.begin(plan)
     sync.after(sync.cuts[0])
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
+    # (4) a plan recorded for a single process (deferred weight gradients: nothing is final at a mark) - built before
+    # GradSync was attached - is exchanged in ONE all-reduce after the pass, never in part
+    import warnings
+    net.flat_g.fill_(float(rank + 1))
+    plan2 = FakePlan()
+    plan2.net, plan2.bwd, plan2.bucket_marks, plan2.defer_wgrad = net, plan.bwd, plan.bucket_marks, True
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter('always')
+        sync.begin(plan2)
+    ok = ok and sync.cuts == [] and any('deferred weight gradients' in str(w.message) for w in wlog)
+    for c in cuts:
+        sync.after(c)                                   # marks the backward run passes: nothing may leave here
+    ok = ok and bool(torch.all(net.flat_g == float(rank + 1)))
+    sync.after(len(plan.bwd))
     sync.finish()
     ok = ok and bool(torch.all(net.flat_g == total / world))
     q.put((rank, ok, cuts))
