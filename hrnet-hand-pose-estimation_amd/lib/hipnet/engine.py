@@ -744,8 +744,15 @@ class Plan(object):
         # the side lanes when the walk reaches that single-lane tail. Their gradients are complete only at the
         # end of the program, so this is off under data parallelism (the bucketed exchange relies on gradients
         # completing in reverse layer order); HRNET_DEFER_WGRAD=0 turns it off.
-        dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not dp and not self.wlane
+        # Data parallelism (recorded at plan build: hipnet.optim.GradSync checks it): only the convolutions of the flat
+        # buffer's LATE region (HipNet._flatten) are deferred - the bucketed exchange relies on every other gradient
+        # completing in reverse layer order, and exchanges the late region when the program ends - and nothing is
+        # offloaded from lane 0. HRNET_DP_PLAN=1 records that form in a single process (bench.py: what the step of
+        # a data-parallel rank costs on one GPU).
+        dp = (torch.distributed.is_available() and torch.distributed.is_initialized()
+              and torch.distributed.get_world_size() > 1) or os.environ.get('HRNET_DP_PLAN', '0') == '1'
+        self.dp_plan = dp
+        self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not self.wlane
                             and os.environ.get('HRNET_DEFER_WGRAD', '1') != '0')
         self.defer_branch_wgrads = os.environ.get('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
         # how much weight-gradient work the single-lane tail can hide: the tail is a stream over the stem / layer1
@@ -755,7 +762,7 @@ class Plan(object):
         tail_pixels = self.N * (self.H // 4) * (self.W // 4)
         self._defer_budget = float(os.environ.get('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
         self._defer_flops = 0.0
-        self.offload_wgrad = self.defer_wgrad and os.environ.get('HRNET_OFFLOAD_WGRAD', '1') != '0'
+        self.offload_wgrad = self.defer_wgrad and not dp and os.environ.get('HRNET_OFFLOAD_WGRAD', '1') != '0'
         self._offload_rr = 0
         self._offload_lanes = set()
         self._deferred = []
@@ -883,6 +890,7 @@ class Plan(object):
                 deferred = (self.batch_wred and self.defer_wgrad and in_region and first_fork is not None
                             and ti > first_fork
                             and (self.defer_branch_wgrads or '.branches.' not in crec.prefix)
+                            and (not self.dp_plan or net.is_late(w))
                             and self._defer_flops + wflops <= self._defer_budget)
                 if deferred:
                     self._defer_flops += wflops

@@ -28,8 +28,17 @@ class HipNet(object):
     def _flatten(self, params):
         # frozen parameters (requires_grad=False, e.g. a fixed softmax temperature) sit behind the trainable
         # ones so that the fused optimiser kernel covers exactly [0, trainable_count)
-        params = [p for p in params if p.requires_grad] + [p for p in params if not p.requires_grad]
+        # ... and, among the trainable ones, the convolution weights whose gradients the backward program may finish
+        # LATE (the deferred weight-gradient launches of the HighResolutionModules: wide branches and fuse layers) sit
+        # behind all the others: [main region, forward order | late region | frozen]. A data-parallel run exchanges
+        # the main region in buckets overlapped with the backward pass (every gradient above a flat offset is final at
+        # a bucket mark) and the late region when the program ends (hipnet.optim.GradSync).
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        self._late_ids = {id(p) for p in params if p.requires_grad and self._is_late(names.get(id(p), ''), p)}
+        params = ([p for p in params if p.requires_grad and id(p) not in self._late_ids]
+                  + [p for p in params if id(p) in self._late_ids] + [p for p in params if not p.requires_grad])
         self.trainable_count = sum(p.numel() for p in params if p.requires_grad)
+        self.late_start = sum(p.numel() for p in params if p.requires_grad and id(p) not in self._late_ids)
         total = sum(p.numel() for p in params)
         self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -52,6 +61,19 @@ class HipNet(object):
 
     def grad_of(self, p):
         return self._gview[id(p)]
+
+    @staticmethod
+    def _is_late(name, p):
+        """conv weights of a HighResolutionModule's wide branches (index >= 2) and fuse layers (see _flatten)"""
+        if p.dim() != 4 or not name.startswith('stage') or not name.endswith('.weight'):
+            return False
+        parts = name.split('.')
+        if 'fuse_layers' in parts:
+            return True
+        return 'branches' in parts and int(parts[parts.index('branches') + 1]) >= 2
+
+    def is_late(self, p):
+        return id(p) in self._late_ids
 
     def _records(self):
         self.convs, self.bns, self.bn_list, self.bias_pad = {}, {}, {}, {}

@@ -107,23 +107,13 @@ class GradSync(object):
     def _prepare(self, plan):
         net = plan.net
         total = net.total_params
-        self.cuts, self._ranges = [], {}
+        self.cuts, self._ranges, self._late = [], {}, None
+        deferred = getattr(plan, 'defer_wgrad', False) or getattr(plan, 'offload_wgrad', False)
+        # recorded for data parallelism (engine.Plan.dp_plan): only gradients of the flat buffer's late region finish
+        # out of order (deferred weight-gradient launches), nothing is offloaded from lane 0
+        dp_ok = bool(getattr(plan, 'dp_plan', False)) and not getattr(plan, 'offload_wgrad', False)
         hi = total
-        pending = 0
-        last = total
-        for op_index, prefix in plan.bucket_marks:
-            w = net.convs[prefix].mod.weight
-            off = net.offsets[id(w)][0]
-            if off > last:        # not monotone: fall back to one exchange at the end
-                self.cuts, self._ranges = [], {}
-                break
-            pending = hi - off
-            last = off
-            if pending * 4 >= self.bucket_bytes:
-                self.cuts.append(op_index)
-                self._ranges[op_index] = (off, hi)
-                hi = off
-        if getattr(plan, 'defer_wgrad', False) or getattr(plan, 'offload_wgrad', False):
+        if deferred and not dp_ok:
             # this plan was recorded for a single process (before init_process_group, or while the default group had
             # one rank): its deferred / offloaded weight-gradient launches finish only when the program ends, so no
             # range is final at a mark - exchange everything once, after the last op
@@ -131,8 +121,26 @@ class GradSync(object):
             warnings.warn('GradSync: the backward program was recorded with deferred weight gradients (single-process '
                           'plan); the gradient is exchanged in one all-reduce after the pass instead of in overlapped '
                           'buckets. Build the model after torch.distributed.init_process_group for the overlapped form.')
-            self.cuts, self._ranges = [], {}
-            hi = total
+            marks = []
+        else:
+            marks = plan.bucket_marks
+            if deferred:
+                hi = int(net.late_start)          # the main region in buckets at the marks, the late region at the end
+                self._late = (hi, total)
+        top = hi
+        last = hi
+        for op_index, prefix in marks:
+            w = net.convs[prefix].mod.weight
+            off = net.offsets[id(w)][0]
+            if off > last:        # not monotone: fall back to one exchange at the end
+                self.cuts, self._ranges = [], {}
+                hi = top
+                break
+            last = off
+            if (hi - off) * 4 >= self.bucket_bytes:
+                self.cuts.append(op_index)
+                self._ranges[op_index] = (off, hi)
+                hi = off
         self._tail = (0, hi)
         self._end = len(plan.bwd)
         self._plan = plan
@@ -146,6 +154,10 @@ class GradSync(object):
         rows.append({'after_op': int(self._end), 'offset': int(self._tail[0]),
                      'floats': int(self._tail[1] - self._tail[0]),
                      'mb': round((self._tail[1] - self._tail[0]) * 4 / 1e6, 2)})
+        if self._late is not None and self._late[1] > self._late[0]:
+            rows.append({'after_op': int(self._end), 'offset': int(self._late[0]),
+                         'floats': int(self._late[1] - self._late[0]),
+                         'mb': round((self._late[1] - self._late[0]) * 4 / 1e6, 2), 'late_region': True})
         return {'payload': 'f32', 'bucket_bytes_min': int(self.bucket_bytes), 'backward_ops': int(self._end),
                 'buckets': rows}
 
@@ -160,10 +172,19 @@ class GradSync(object):
         rng = self._ranges.get(op_index)
         if rng is None and op_index == self._end:
             rng = self._tail
-        if rng is None or rng[1] <= rng[0] or op_index in self._done:
+        if rng is None or op_index in self._done:
             return
         self._done.add(op_index)
-        self._works.append(self.dist.all_reduce(net.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
+        if rng[1] > rng[0]:
+            self._works.append(self.dist.all_reduce(net.flat_g[rng[0]:rng[1]], group=self.pg, async_op=True))
+        if op_index == self._end and self._late is not None and self._late[1] > self._late[0]:
+            # (the late region: its deferred weight-gradient launches were joined into this stream by the program's
+            # last ops; in two halves so that the first travels while the second is being queued)
+            lo, hi = self._late
+            mid = lo + (hi - lo) // 2
+            for a, b in ((lo, mid), (mid, hi)):
+                if b > a:
+                    self._works.append(self.dist.all_reduce(net.flat_g[a:b], group=self.pg, async_op=True))
 
     def finish(self):
         """wait for the exchanges of this step; any bucket whose mark the backward run did not pass (it was

@@ -12,6 +12,12 @@ def canon(name):
             body = name[name.index('<') + 1:name.rindex('>')]
             ints = [q.strip() for q in body.split(',')][1:]
         return '|'.join(['bwd_fused'] + ints)
+    if 'conv_ring_kernel' in name:
+        if name.startswith('_ZN'):
+            ints = re.findall(r'Li(\d+)E', name) + ['true' if 'Lb1E' in name else 'false']
+        else:
+            ints = [q.strip() for q in name[name.index('<') + 1:name.rindex('>')].split(',')]
+        return '|'.join(['conv_ring'] + ints)
     if 'bwd_pw_kernel' in name:
         ints = re.findall(r'Li(\d+)E', name) if name.startswith('_ZN') else [q.strip() for q in name[name.index('<') + 1:name.rindex('>')].split(',')]
         return '|'.join(['bwd_pw'] + ints)

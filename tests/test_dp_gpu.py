@@ -15,11 +15,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, 'hrnet-hand-pose-estimation_amd')
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, atomic='0'):
     try:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
-        os.environ['HRNET_DETERMINISTIC'] = '1'      # the test compares two runs bit for bit
+        os.environ['HRNET_DETERMINISTIC'] = '1'      # ordered batch statistics: the two runs see the same activations
+        # atomic '0': weight gradients through slabs + ordered sums, the two runs are compared bit for bit;
+        # '1': by float atomics into the flat gradient (the default of a training run), compared to f32 summation noise
+        os.environ['HRNET_WGRAD_ATOMIC'] = atomic
         for p in (REPO, os.path.join(PKG, 'lib')):
             if p not in sys.path:
                 sys.path.insert(0, p)
@@ -40,7 +43,7 @@ def _worker(rank, world, port, q):
         model.load_state_dict(sd)
         model = model.cuda().train()
         opt = torch.optim.SGD(model.parameters(), lr=0.1)              # no grad_scale: finish() must average
-        sync = GradSync(model, optimizer=opt, bucket_bytes=8 << 20)    # small buckets: several overlapped exchanges
+        sync = GradSync(model, optimizer=opt, bucket_bytes=2 << 20)    # small buckets: several overlapped exchanges over the main region
         net = model.hip()
         ps = [torch.empty_like(net.flat_p) for _ in range(world)]
         dist.all_gather(ps, net.flat_p)
@@ -72,7 +75,19 @@ def _worker(rank, world, port, q):
             torch.cuda.synchronize()
             got = net.flat_g
             errs.append(float((got - want).abs().max()))
-            same = same and bool(torch.equal(got, want))
+            if atomic == '0':
+                same = same and bool(torch.equal(got, want))
+            else:
+                rel = float((got - want).norm() / want.norm())
+                errs.append(rel)
+                same = same and rel <= 2e-5
+        # the backward program was recorded FOR data parallelism (the process group was up when the plan was built):
+        # weight-gradient launches are deferred to the single-lane tail only in the flat buffer's late region, which
+        # leaves in its own exchange when the pass ends
+        plan = sync._plan
+        late = [b for b in sync.describe()['buckets'] if b.get('late_region')]
+        same = same and plan.wgrad_atomic == (atomic == '1') and plan.dp_plan and plan.defer_wgrad and not plan.offload_wgrad and plan.n_deferred_wgrads > 20
+        same = same and len(late) == 1 and late[0]['offset'] == net.late_start and late[0]['floats'] > 10_000_000
         q.put((rank, same, len(sync.cuts), errs))
         dist.destroy_process_group()
     except Exception as e:   # surface the failure in the parent
@@ -80,12 +95,13 @@ def _worker(rank, world, port, q):
         q.put((rank, False, -1, traceback.format_exc()))
 
 
-def test_two_rank_gradient_exchange_on_the_recorded_backward():
+@pytest.mark.parametrize('atomic', ['0', '1'])
+def test_two_rank_gradient_exchange_on_the_recorded_backward(atomic):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 300)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port + int(atomic), q, atomic)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

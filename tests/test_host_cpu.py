@@ -285,6 +285,26 @@ def _gradsync_worker(rank, world, port, q):
     sync.after(len(plan.bwd))
     sync.finish()
     ok = ok and bool(torch.all(net.flat_g == total / world))
+    # (5) a plan recorded FOR data parallelism (engine.Plan.dp_plan): the deferred launches only touch the flat buffer's
+    # late region [late_start, total) - the main region goes in buckets at the marks, the late one when the pass ends
+    net.flat_g.fill_(float(rank + 1))
+    net.late_start = 4000                                # layers 4, 5 sit in the late region; marks cover l0..l3
+    plan3 = FakePlan()
+    plan3.net, plan3.bwd, plan3.defer_wgrad, plan3.dp_plan = net, plan.bwd, True, True
+    plan3.bucket_marks = [((4 - i) * 10, 'l{}'.format(i)) for i in range(3, -1, -1)]
+    sync.begin(plan3)
+    d = sync.describe()
+    ok = ok and len(sync.cuts) >= 1 and [b for b in d['buckets'] if b.get('late_region')][0]['offset'] == 4000
+    spans = sorted((b['offset'], b['offset'] + b['floats']) for b in d['buckets'])
+    ok = ok and spans[0][0] == 0 and spans[-1][1] == 6000 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sync.after(sync.cuts[0])
+    for w_ in sync._works:
+        w_.wait()
+    ok = ok and bool(torch.all(net.flat_g[4000:] == float(rank + 1)))      # the late region has not left yet
+    for c in sync.cuts[1:] + [len(plan3.bwd)]:
+        sync.after(c)
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
     q.put((rank, ok, cuts))
     dist.destroy_process_group()
 
