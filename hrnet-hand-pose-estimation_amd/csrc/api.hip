@@ -57,6 +57,8 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_CONV_SUM: e = hr_launch_conv_sum(op, s); break;
     case HR_OP_BN_FINALIZE_TABLE: e = hr_launch_bn_finalize_table(op, s); break;
     case HR_OP_EW_TABLE: e = hr_launch_ew_table(op, s); break;
+    case HR_OP_HEAD_MIX: e = hr_launch_head_mix(op, s); break;
+    case HR_OP_UPSAMPLE_T: e = hr_launch_upsample_t(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");
@@ -319,6 +321,31 @@ extern "C" int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* 
   op.p[0] = (void*)dcat;
   for (int k = 0; k < nbr; ++k) op.p[1 + k] = dxs[k];
   return hr_launch_bilinear_cat_bwd(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_head_mix(int dtype, const void* x0, const void* w0, const float* bias, void* y, float* stats,
+                              int rows_mode, const void* const* ts, const int* hs, const int* ws, int nup, int N, int H,
+                              int W, int C0, int Cout, int align_corners, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_HEAD_MIX);
+  HR_REQUIRE(nup >= 0 && nup <= 3 && (nup == 0 || (ts && hs && ws)), "head_mix: args");
+  const int iv[8] = {dtype, N, H, W, C0, Cout, nup, align_corners};
+  memcpy(op.i, iv, sizeof(iv));
+  op.i[14] = rows_mode;
+  op.p[0] = (void*)x0; op.p[1] = (void*)w0; op.p[2] = (void*)bias; op.p[3] = y; op.p[4] = stats;
+  for (int k = 0; k < nup; ++k) {
+    op.i[8 + 2 * k] = hs[k]; op.i[9 + 2 * k] = ws[k];
+    op.p[5 + k] = (void*)ts[k];
+  }
+  return hr_launch_head_mix(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_upsample_bilinear_t(int dtype, const void* g, void* out, int N, int H, int W, int C, int hs,
+                                         int ws, int align_corners, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_UPSAMPLE_T);
+  const int iv[8] = {dtype, N, H, W, C, hs, ws, align_corners};
+  memcpy(op.i, iv, sizeof(iv));
+  op.p[0] = (void*)g; op.p[1] = out;
+  return hr_launch_upsample_t(op, (hipStream_t)stream);
 }
 
 extern "C" int hrnet_im2col_stem(int dtype, const float* img_nchw, void* cols, int N, int C, int H, int W,

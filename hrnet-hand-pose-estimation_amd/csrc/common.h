@@ -107,6 +107,26 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
+// source taps of one destination coordinate of F.interpolate(mode='bilinear') (PyTorch's
+// area_pixel_compute_source_index): the two source indices and the weight of the second one
+__device__ __forceinline__ void bilin_src(int d, int in_size, int out_size, int align, int& i0, int& i1,
+                                          float& l1) {
+  float src;
+  if (align) {
+    // PyTorch area_pixel_compute_source_index(align_corners=True): src = d * (in-1)/(out-1)
+    src = out_size > 1 ? (float)d * ((float)(in_size - 1) / (float)(out_size - 1)) : 0.f;
+  } else {
+    // align_corners=False: src = (d+0.5)*scale-0.5, clamp >= 0
+    const float scale = (float)in_size / (float)out_size;
+    src = ((float)d + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
 // Batch statistics kept as 8 partial copies sums[8][2][C] (sum y, sum y^2): producers add their per-workgroup sums
 // with float atomics into copy (workgroup id & 7); consumers turn them into the BatchNorm affine on the fly, so
 // no finalize launch sits between a conv and the ops that read its output. The SAME function serves the
@@ -214,3 +234,5 @@ int hr_gemm_pw(const void* x, const void* w, const float* bias, void* y, float* 
                int Cout, hipStream_t s);
 int hr_launch_bn_finalize_table(const HrOp& op, hipStream_t s);
 int hr_launch_ew_table(const HrOp& op, hipStream_t s);
+int hr_launch_head_mix(const HrOp& op, hipStream_t s);
+int hr_launch_upsample_t(const HrOp& op, hipStream_t s);

@@ -490,24 +490,6 @@ struct CatArgs {
   int align;   // align_corners=True (pose_hrnet_softmax.py:499-501) instead of False (pose_hrnet.py:560-562)
 };
 
-__device__ __forceinline__ void bilin_src(int d, int in_size, int out_size, int align, int& i0, int& i1,
-                                          float& l1) {
-  float src;
-  if (align) {
-    // PyTorch area_pixel_compute_source_index(align_corners=True): src = d * (in-1)/(out-1)
-    src = out_size > 1 ? (float)d * ((float)(in_size - 1) / (float)(out_size - 1)) : 0.f;
-  } else {
-    // align_corners=False: src = (d+0.5)*scale-0.5, clamp >= 0
-    const float scale = (float)in_size / (float)out_size;
-    src = ((float)d + 0.5f) * scale - 0.5f;
-    if (src < 0.f) src = 0.f;
-  }
-  i0 = (int)src;
-  if (i0 > in_size - 1) i0 = in_size - 1;
-  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_cat_kernel(CatArgs a) {
   constexpr int VEC = TT<T>::VEC;
@@ -810,7 +792,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const HrPackEnt* tab, i
     const int rows = e.Cout_pad - co0 < nr ? e.Cout_pad - co0 : nr;
     for (int i = threadIdx.x; i < rows * rowlen; i += 256) {      // consecutive master rows are contiguous
       const int r = i / rowlen;
-      buf[i] = co0 + r < e.Cout ? w[(size_t)co0 * rowlen + i] : 0.f;
+      buf[i] = co0 + r < e.Cout ? w[e.ld ? (size_t)(co0 + r) * e.ld + (i - r * rowlen) : (size_t)co0 * rowlen + i] : 0.f;
     }
     __syncthreads();
     T* o = out + (size_t)co0 * olen;
@@ -914,8 +896,10 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* parti
 // lanes in a fixed order (deterministic).
 __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* grad, int nsplit, int Cout, int Cin,
                                                    int ks, int Cout_real, int Cin_real, int kflat, int accumulate,
-                                                   long long base, float (*red)[64]) {
+                                                   long long base, float (*red)[64], int ld = 0) {
   const int taps = ks * ks;
+  // ld: floats between consecutive output-channel rows of `grad` (a column slice of a wider 1x1 weight); 0 = dense
+  const size_t gpitch = ld ? (size_t)ld : (size_t)Cin_real * taps;
   const long long total = (long long)Cout_real * Cin_real * taps;
   const size_t slab_sz = (size_t)Cout * (kflat ? 1 : taps) * Cin;
   const bool vec = ((Cin_real | Cin) & 3) == 0;
@@ -955,7 +939,7 @@ __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* gr
         const int ci1 = (int)(id1 % Cin_real);
         const int t1 = (int)((id1 / Cin_real) % taps);
         const int co1 = (int)(id1 / ((long long)Cin_real * taps));
-        float* g = grad + ((size_t)co1 * Cin_real + ci1) * taps + t1;
+        float* g = grad + (size_t)co1 * gpitch + (size_t)ci1 * taps + t1;
         *g = accumulate ? *g + sacc : sacc;
       }
     }
@@ -983,7 +967,7 @@ __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* gr
   __syncthreads();
   if (sl == 0 && ok) {
     const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-    float* g = grad + ((size_t)co * Cin_real + ci) * taps + t;
+    float* g = grad + (size_t)co * gpitch + (size_t)ci * taps + t;
     *g = accumulate ? *g + s : s;
   }
   __syncthreads();
@@ -991,11 +975,11 @@ __device__ __forceinline__ void wgrad_reduce_chunk(const float* slabs, float* gr
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* grad, int nsplit,
                                                            int Cout, int Cin, int ks, int Cout_real,
-                                                           int Cin_real, int kflat, int accumulate) {
+                                                           int Cin_real, int kflat, int accumulate, int ld) {
   __shared__ __attribute__((aligned(16))) float red[16][64];
   const long long total = (long long)Cout_real * Cin_real * ks * ks;
   for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64)
-    wgrad_reduce_chunk(slabs, grad, nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, accumulate, base, red);
+    wgrad_reduce_chunk(slabs, grad, nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, accumulate, base, red, ld);
 }
 
 // every weight gradient of a backward segment in ONE launch: block b finds its layer by binary search
@@ -1008,7 +992,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_kernel(const HrWredEnt
   }
   const HrWredEnt e = tab[lo];
   wgrad_reduce_chunk(e.slabs, e.grad, e.nsplit, e.Cout_pad, e.Cin_pad, e.ks, e.Cout, e.Cin, e.kflat, e.accumulate,
-                     (long long)((int)blockIdx.x - e.block0) * 64, red);
+                     (long long)((int)blockIdx.x - e.block0) * 64, red, e.ld);
 }
 
 // every BatchNorm of a forward pass in ONE launch: batch sums -> the arrays the backward pass reads (scale, shift,
@@ -1254,6 +1238,96 @@ int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s) {
   return hr_check_launch("bn_bwd_finalize");
 }
 
+
+// Transpose of a bilinear upsampling over ALL channels (the head without its concat, gemm_pw.hip): g[n][h][w][c] =
+// sum over the H x W pixels (Y, X) whose bilinear footprint touches (h, w) of weight * G[n][Y][X][c]. Separable and
+// streamed: a thread owns one low-resolution column w and one 16-byte channel vector, walks the full-resolution
+// rows Y of its workgroup's band in order, forms the row's x-contraction (the <= 2*scale+1 pixels whose x taps hit w;
+// weights evaluated once per thread) and adds it into the two low-resolution rows Y touches, which live in
+// registers and are stored as the walk leaves them. Every element of G is read once per band it belongs to (bands
+// overlap by the footprint of their border rows), with unit-stride 16-byte loads across the channel vectors.
+struct UpTArgs {
+  const char* g;   // [N][H][W][C]
+  char* out;       // [N][hs][ws][C]
+  int N, H, W, C, hs, ws, align;
+  int cvw;         // channel vectors per workgroup
+  int chunks;      // channel chunks
+  int rband;       // low-resolution rows per workgroup
+  int bands;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_t_kernel(UpTArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const int cvtot = a.C / VEC;
+  int b = blockIdx.x;
+  const int chunk = b % a.chunks; b /= a.chunks;
+  const int band = b % a.bands;
+  const int n = b / a.bands;
+  const int cv = chunk * a.cvw + (int)threadIdx.x % a.cvw;
+  const int w = (int)threadIdx.x / a.cvw;
+  if (w >= a.ws || cv >= cvtot) return;
+  const int h_lo = band * a.rband, h_hi = min(a.hs, h_lo + a.rband);
+  // x window of column w and its weights (zero entries are skipped in the walk)
+  int dx0, dx1;
+  bilin_window(w, a.ws, a.W, a.align, dx0, dx1);
+  float wxs[CATB_MAXW];
+#pragma unroll
+  for (int j = 0; j < CATB_MAXW; ++j) {
+    const int dx = dx0 + j;
+    int x0, x1;
+    float lx;
+    bilin_src(dx < a.W ? dx : a.W - 1, a.ws, a.W, a.align, x0, x1, lx);
+    const float wx = (x0 == w ? 1.f - lx : 0.f) + (x1 == w ? lx : 0.f);
+    wxs[j] = (dx < dx1 && dx < a.W) ? wx : 0.f;
+  }
+  // full-resolution rows whose taps reach [h_lo, h_hi)
+  int ya, yb, t0, t1;
+  bilin_window(h_lo, a.hs, a.H, a.align, ya, t1);
+  bilin_window(h_hi - 1, a.hs, a.H, a.align, t0, yb);
+  float acc0[VEC], acc1[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc0[k] = acc1[k] = 0.f;
+  int cur = h_lo;      // acc0 belongs to low-resolution row cur, acc1 to cur + 1
+  const char* gbase = a.g + ((size_t)n * a.H * a.W * a.C + (size_t)cv * VEC) * sizeof(T);
+  char* obase = a.out + ((size_t)n * a.hs * a.ws * a.C + (size_t)w * a.C + (size_t)cv * VEC) * sizeof(T);
+  auto flush = [&]() {
+    if (cur >= h_lo && cur < h_hi) *(V16*)(obase + (size_t)cur * a.ws * a.C * sizeof(T)) = v16_pack<T>(acc0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { acc0[k] = acc1[k]; acc1[k] = 0.f; }
+    ++cur;
+  };
+  for (int Y = ya; Y < yb; ++Y) {
+    int y0, y1;
+    float ly;
+    bilin_src(Y, a.hs, a.H, a.align, y0, y1, ly);
+    if (y1 < h_lo || y0 >= h_hi) continue;
+    while (cur < y0) flush();            // (y0 never decreases along Y)
+    float r[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r[k] = 0.f;
+    const char* row = gbase + ((size_t)Y * a.W + dx0) * a.C * sizeof(T);
+#pragma unroll
+    for (int j = 0; j < CATB_MAXW; ++j) {
+      if (wxs[j] != 0.f) {
+        float gv[VEC];
+        v16_unpack<T>(*(const V16*)(row + (size_t)j * a.C * sizeof(T)), gv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = fmaf(wxs[j], gv[k], r[k]);
+      }
+    }
+    const float wa = y1 != y0 ? 1.f - ly : 1.f, wb = y1 != y0 ? ly : 0.f;
+    if (y0 == cur) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { acc0[k] = fmaf(wa, r[k], acc0[k]); acc1[k] = fmaf(wb, r[k], acc1[k]); }
+    } else {             // y0 == cur - 1 cannot happen (flushed up to y0); y0 < h_lo: only the upper tap is ours
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc0[k] = fmaf(wb, r[k], acc0[k]);
+    }
+  }
+  while (cur < h_hi) flush();
+}
+
 static int fill_cat_args(const HrOp& op, CatArgs& a, bool bwd) {
   a.nbr = op.i[1]; a.N = op.i[2]; a.H = op.i[3]; a.W = op.i[4];
   HR_REQUIRE(a.nbr >= 1 && a.nbr <= 4, "bilinear_cat: nbr=%d", a.nbr);
@@ -1274,6 +1348,35 @@ static int fill_cat_args(const HrOp& op, CatArgs& a, bool bwd) {
   a.accumulate = bwd ? op.i[17] : 0;
   a.align = op.f[0] != 0.f;   // (all integer slots are taken)
   return 0;
+}
+
+// slots: i = {dtype, N, H, W, C, hs, ws, align}, p = {G [N][H][W][C], out [N][hs][ws][C]}
+int hr_launch_upsample_t(const HrOp& op, hipStream_t s) {
+  UpTArgs a;
+  a.g = (const char*)op.p[0]; a.out = (char*)op.p[1];
+  a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.hs = op.i[5]; a.ws = op.i[6]; a.align = op.i[7];
+  const int vec = op.i[0] == HR_F32 ? 4 : 8;
+  HR_REQUIRE(op.i[0] == HR_F32 || op.i[0] == HR_BF16, "upsample_t: dtype");
+  HR_REQUIRE(a.g && a.out && a.N > 0 && a.C > 0 && a.C % vec == 0, "upsample_t: args");
+  HR_REQUIRE(a.hs >= 1 && a.ws >= 1 && a.hs <= a.H && a.ws <= a.W && a.ws <= 256, "upsample_t: %dx%d from %dx%d",
+             a.hs, a.ws, a.H, a.W);
+  HR_REQUIRE(2 * ((a.W + a.ws - 1) / a.ws) + 4 <= CATB_MAXW, "upsample_t: scale %d x %d too large", a.W, a.ws);
+  const int cvtot = a.C / vec;
+  a.cvw = 256 / a.ws;
+  if (a.cvw > cvtot) a.cvw = cvtot;
+  if (a.cvw < 1) a.cvw = 1;
+  a.chunks = (cvtot + a.cvw - 1) / a.cvw;
+  // ~16 full-resolution rows per band
+  a.rband = (16 * a.hs + a.H - 1) / a.H;
+  if (a.rband < 1) a.rband = 1;
+  a.bands = (a.hs + a.rband - 1) / a.rband;
+  const long long blocks = (long long)a.N * a.bands * a.chunks;
+  HR_REQUIRE(blocks < (1ll << 31), "upsample_t: grid");
+  if (op.i[0] == HR_F32)
+    hipLaunchKernelGGL(upsample_t_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(upsample_t_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hr_check_launch("upsample_t");
 }
 
 int hr_launch_bilinear_cat(const HrOp& op, hipStream_t s) {
@@ -1399,7 +1502,7 @@ int hr_launch_wgrad_reduce(const HrOp& op, hipStream_t s) {
   long long rgrid = (total + 63) / 64;
   if (rgrid > 4096) rgrid = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)op.p[0],
-                     (float*)op.p[1], nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, op.i[7]);
+                     (float*)op.p[1], nsplit, Cout, Cin, ks, Cout_real, Cin_real, kflat, op.i[7], op.i[8]);
   return hr_check_launch("wgrad_reduce");
 }
 

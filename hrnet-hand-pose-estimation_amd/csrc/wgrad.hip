@@ -34,6 +34,7 @@ struct WgradArgs {
   // with float atomics (no slabs, no reduce launch). 3x3: the tile goes through LDS so that a wave instruction adds
   // 64 consecutive floats of one output channel's [ci][tap] run
   int atomic, Cout_real, Cin_real;
+  int ld;   // floats between consecutive output-channel rows of the gradient (1x1 launches into a column slice)
 };
 
 // lane's KSTEP-deep operand fragment for 16 channels starting at byte offset `choff` of each
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const float v4[4] = {acc[j][f].x, acc[j][f].y, acc[j][f].z, acc[j][f].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (co + r < a.Cout_real && ci < a.Cin_real) atomicAdd(a.slabs + (size_t)(co + r) * a.Cin_real + ci, v4[r]);
+              if (co + r < a.Cout_real && ci < a.Cin_real) atomicAdd(a.slabs + (size_t)(co + r) * a.ld + ci, v4[r]);
           }
         }
       }
@@ -397,6 +398,9 @@ int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.in_relu = op.i[10];
   a.atomic = op.i[12]; a.Cout_real = op.i[13]; a.Cin_real = op.i[14];
+  a.ld = op.i[15] ? op.i[15] : a.Cin_real;
+  HR_REQUIRE(!op.i[15] || (a.atomic && ks == 1 && op.i[15] >= a.Cin_real),
+             "wgrad: a row pitch (%d) belongs to an atomic 1x1 launch", op.i[15]);
   HR_REQUIRE(!a.atomic || (a.Cout_real >= 1 && a.Cout_real <= Cout && a.Cin_real >= 1 && a.Cin_real <= Cin),
              "wgrad: the atomic form needs the gradient's real channel counts (%d, %d)", a.Cout_real, a.Cin_real);
   dim3 grid((unsigned)nsplit, (unsigned)((Cout + c.bco - 1) / c.bco), (unsigned)((Cin + c.kc - 1) / c.kc));

@@ -26,20 +26,22 @@ OP_PACK_TABLE, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_WGRAD_REDUCE_TABLE, OP_BWD_FU
 OP_BWD_PW = 23
 OP_CONV_SUM = 24
 OP_EW_TABLE = 25
+OP_HEAD_MIX = 26
+OP_UPSAMPLE_T = 27
 LANE_SLOT = 18
 
 
 class HrPackEnt(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p), ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32),
                 ('ks', ctypes.c_int32), ('Cout_pad', ctypes.c_int32), ('Cin_pad', ctypes.c_int32),
-                ('mode', ctypes.c_int32), ('block0', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('mode', ctypes.c_int32), ('block0', ctypes.c_int32), ('ld', ctypes.c_int32)]
 
 
 class HrWredEnt(ctypes.Structure):
     _fields_ = [('slabs', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('nsplit', ctypes.c_int32),
                 ('Cout_pad', ctypes.c_int32), ('Cin_pad', ctypes.c_int32), ('ks', ctypes.c_int32),
                 ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32), ('kflat', ctypes.c_int32),
-                ('accumulate', ctypes.c_int32), ('block0', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('accumulate', ctypes.c_int32), ('block0', ctypes.c_int32), ('ld', ctypes.c_int32)]
 
 
 class HrBnEnt(ctypes.Structure):
@@ -117,6 +119,10 @@ _SIGS = {
     'hrnet_bn_bwd_finalize': [_c_vp, _c_int, _c_int, _c_float] + [_c_vp] * 6 + [_c_int, _c_vp],
     'hrnet_bilinear_cat': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 5 + [_c_vp],
     'hrnet_bilinear_cat_bwd': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 6 + [_c_vp],
+    'hrnet_head_mix': [_c_int] + [_c_vp] * 5 + [_c_int, _pp, _ip, _ip] + [_c_int] * 7 + [_c_vp],
+    'hrnet_head_mix_rows': [_c_int] * 3,
+    'hrnet_head_mix_supported': [_c_int] * 3,
+    'hrnet_upsample_bilinear_t': [_c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
     'hrnet_gaussian_targets': [_c_vp] * 3 + [_c_int] * 3 + [_c_float, _c_vp],
     'hrnet_normalize_u8': [_c_vp, _c_vp] + [_c_int] * 3 + [ctypes.POINTER(ctypes.c_float)] * 2 + [_c_vp],
     'hrnet_spatial_softmax_fwd': [_c_vp] * 3 + [_c_int] * 2 + [_c_vp],
@@ -141,7 +147,8 @@ _SIGS = {
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
-          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks'}
+          'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks',
+          'hrnet_head_mix_rows', 'hrnet_head_mix_supported'}
 EXPORTED = sorted(list(_SIGS) + ['hrnet_last_error_string', 'hrnet_event_create'])
 
 _lib = None

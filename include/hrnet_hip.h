@@ -69,10 +69,13 @@ enum {
   HR_OP_BN_FINALIZE_TABLE = 22, /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
   HR_OP_BWD_PW = 23,       /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
   HR_OP_CONV_SUM = 24,     /* hrnet_conv2d_sum */
-  HR_OP_EW_TABLE = 25      /* several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE jobs as ONE launch:
+  HR_OP_EW_TABLE = 25,     /* several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE jobs as ONE launch:
                               p[0] = device array of HrOp jobs (slots as for the single op; i[16] = first block of the
                               job, i[17] = its blocks: hrnet_ew_table_blocks()), i[0] = jobs, i[1] = total blocks,
                               i[2] = kind of the jobs, i[3] = dtype */
+  HR_OP_HEAD_MIX = 26,     /* hrnet_head_mix: i = {dtype, N, H, W, C0, Cout, nup, align, h1, w1, h2, w2, h3, w3, rows
+                              mode}, p = {x0, w0 packed, bias, y, statistics, t1, t2, t3} */
+  HR_OP_UPSAMPLE_T = 27    /* hrnet_upsample_bilinear_t: i = {dtype, N, H, W, C, hs, ws, align}, p = {G, out} */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -288,7 +291,9 @@ int hrnet_pack_weights(int dtype, const float* w_oihw, void* packed, int Cout, i
 typedef struct HrPackEnt {
   const void* w;   /* f32 OIHW master weights */
   void* out;       /* packed weights */
-  int32_t Cout, Cin, ks, Cout_pad, Cin_pad, mode, block0, reserved;
+  int32_t Cout, Cin, ks, Cout_pad, Cin_pad, mode, block0;
+  int32_t ld;      /* mode 0: floats between consecutive output-channel rows of w (a column slice of a wider 1x1
+                      weight); 0 = dense OIHW */
 } HrPackEnt;
 int hrnet_pack_weights_table(int dtype, const HrPackEnt* table, int n, int total_blocks,
                              hr_stream_t stream);
@@ -301,7 +306,8 @@ int hrnet_pack_blocks(int Cout_pad, int Cin_pad, int ks, int mode);
 typedef struct HrWredEnt {
   const float* slabs; /* [nsplit][Cout_pad][taps][Cin_pad] (kflat: [nsplit][Cout_pad][Cin_pad]) */
   float* grad;        /* OIHW f32 [Cout][Cin][ks][ks] */
-  int32_t nsplit, Cout_pad, Cin_pad, ks, Cout, Cin, kflat, accumulate, block0, reserved;
+  int32_t nsplit, Cout_pad, Cin_pad, ks, Cout, Cin, kflat, accumulate, block0;
+  int32_t ld;         /* floats between consecutive output-channel rows of grad (column slice); 0 = dense */
 } HrWredEnt;
 int hrnet_wgrad_reduce_table(const HrWredEnt* table, int n, int total_blocks, hr_stream_t stream);
 
@@ -418,6 +424,27 @@ int hrnet_bilinear_cat(int dtype, void* cat, const void* const* xs, const int* h
 int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const int* hs,
                            const int* ws, const int* cs, int nbr, int N, int H, int W,
                            int align_corners, int accumulate, hr_stream_t stream);
+
+/*
+ * The head without its concat (pose_hrnet.py:560-566: F.upsample x3, torch.cat, last_layer[0] = Conv2d(480, 480, 1)).
+ * A 1x1 convolution commutes with bilinear upsampling, so
+ *     last_layer[0](cat(x0, up(x1), up(x2), up(x3))) = W0 x0 + up(W1 x1) + up(W2 x2) + up(W3 x3) + bias,
+ * W_j = the columns of the weight that multiply branch j. The products t_j = W_j x_j are plain hrnet_conv2d launches
+ * at branch j's resolution; hrnet_head_mix forms W0 x0 on the full-resolution grid, adds the bias and the bilinear
+ * upsampling of t_1..t_nup (align_corners as hrnet_bilinear_cat), stores y once and gathers its batch statistics:
+ *   rows_mode 0: stats = sums[8][2][Cout] (float atomics, as hrnet_conv2d with stats_atomic)
+ *   rows_mode 1: stats = rows[hrnet_head_mix_rows(N,H,W)][2][Cout], one row per workgroup (deterministic)
+ * bf16, C0 a multiple of 32, Cout <= 512 (hrnet_head_mix_supported). w0: hrnet_pack_weights layout [Cout][C0].
+ */
+int hrnet_head_mix(int dtype, const void* x0, const void* w0, const float* bias, void* y, float* stats, int rows_mode,
+                   const void* const* ts, const int* hs, const int* ws, int nup, int N, int H, int W, int C0, int Cout,
+                   int align_corners, hr_stream_t stream);
+int hrnet_head_mix_rows(int N, int H, int W);
+int hrnet_head_mix_supported(int dtype, int C0, int Cout);
+/* out[N,hs,ws,C] = bilinear^T(G[N,H,W,C]) over ALL channels: the gradient of t_j above (autograd of F.upsample,
+ * pose_hrnet.py:561-563). Separable, streamed over the rows of G; deterministic. */
+int hrnet_upsample_bilinear_t(int dtype, const void* g, void* out, int N, int H, int W, int C, int hs, int ws,
+                              int align_corners, hr_stream_t stream);
 
 /* stem: NCHW f32 image -> im2col rows [N,Ho,Wo,Kpad] (k = (r*3+s)*C + c), 3x3 stride 2 pad 1
  * (conv1, pose_hrnet.py:283-284,512). */
