@@ -10,7 +10,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libhrnet_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'conv_bs.hip', 'conv_fwd.hip', 'conv_dg.hip', 'conv_fwdb.hip', 'conv_fwds.hip', 'conv_ring.hip', 'wgrad.hip', 'bwd_fused.hip', 'bwd_pw.hip', 'gemm_pw.hip', 'eltwise.hip', 'loss.hip', 'dcn.hip']
+SOURCES = ['api.hip', 'conv.hip', 'conv_bs.hip', 'conv_fwd.hip', 'conv_dg.hip', 'conv_fwdb.hip', 'conv_fwds.hip', 'conv_ring.hip', 'wgrad.hip', 'bwd_fused.hip', 'bwd_pw.hip', 'gemm_pw.hip', 'head_mix.hip', 'eltwise.hip', 'loss.hip', 'dcn.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_body.h'), os.path.join(CSRC, 'conv_ring.h'), os.path.join(REPO, 'include', 'hrnet_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
@@ -20,7 +20,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
 # per-file extra flags. conv_ring.hip: no SLP vectorisation - the v_pk_fma_f32 / v_pk_add_f32 pairs it forms out of
 # the epilogue's scalar f32 arithmetic returned wrong sums for the last 16 lanes of a wave now and then (backward
 # statistics, run-to-run different), and packed f32 next to MFMAs is slower anyway (MI355X_MICROARCH.md)
-EXTRA = {'conv_ring.hip': ['-fno-slp-vectorize']}
+EXTRA = {'conv_ring.hip': ['-fno-slp-vectorize'], 'head_mix.hip': ['-fno-slp-vectorize']}
 
 
 def _stamp(src):

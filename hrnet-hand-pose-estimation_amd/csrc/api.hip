@@ -339,12 +339,19 @@ extern "C" int hrnet_head_mix(int dtype, const void* x0, const void* w0, const f
   return hr_launch_head_mix(op, (hipStream_t)stream);
 }
 
-extern "C" int hrnet_upsample_bilinear_t(int dtype, const void* g, void* out, int N, int H, int W, int C, int hs,
-                                         int ws, int align_corners, hr_stream_t stream) {
+extern "C" int hrnet_upsample_bilinear_t(int dtype, const void* g, void* const* outs, const int* hs, const int* ws,
+                                         int nout, int N, int H, int W, int C, int align_corners, int streamed,
+                                         hr_stream_t stream) {
   OP_BEGIN(HR_OP_UPSAMPLE_T);
-  const int iv[8] = {dtype, N, H, W, C, hs, ws, align_corners};
+  HR_REQUIRE(nout >= 1 && nout <= 3 && outs && hs && ws, "upsample_t: args");
+  const int iv[7] = {dtype, N, H, W, C, nout, align_corners};
   memcpy(op.i, iv, sizeof(iv));
-  op.p[0] = (void*)g; op.p[1] = out;
+  op.i[13] = streamed;
+  op.p[0] = (void*)g;
+  for (int k = 0; k < nout; ++k) {
+    op.p[1 + k] = outs[k];
+    op.i[7 + 2 * k] = hs[k]; op.i[8 + 2 * k] = ws[k];
+  }
   return hr_launch_upsample_t(op, (hipStream_t)stream);
 }
 

@@ -1350,32 +1350,46 @@ static int fill_cat_args(const HrOp& op, CatArgs& a, bool bwd) {
   return 0;
 }
 
-// slots: i = {dtype, N, H, W, C, hs, ws, align}, p = {G [N][H][W][C], out [N][hs][ws][C]}
+// slots: i = {dtype, N, H, W, C, nout, align, h1, w1, h2, w2, h3, w3}, p = {G [N][H][W][C], out_k [N][h_k][w_k][C]}
+int hr_upsample_t_tile(int dtype, const void* g, void* const* outs, const int* hs, const int* ws, int nout, int N, int H,
+                       int W, int C, int align, hipStream_t s);
+
 int hr_launch_upsample_t(const HrOp& op, hipStream_t s) {
-  UpTArgs a;
-  a.g = (const char*)op.p[0]; a.out = (char*)op.p[1];
-  a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.hs = op.i[5]; a.ws = op.i[6]; a.align = op.i[7];
-  const int vec = op.i[0] == HR_F32 ? 4 : 8;
-  HR_REQUIRE(op.i[0] == HR_F32 || op.i[0] == HR_BF16, "upsample_t: dtype");
-  HR_REQUIRE(a.g && a.out && a.N > 0 && a.C > 0 && a.C % vec == 0, "upsample_t: args");
-  HR_REQUIRE(a.hs >= 1 && a.ws >= 1 && a.hs <= a.H && a.ws <= a.W && a.ws <= 256, "upsample_t: %dx%d from %dx%d",
-             a.hs, a.ws, a.H, a.W);
-  HR_REQUIRE(2 * ((a.W + a.ws - 1) / a.ws) + 4 <= CATB_MAXW, "upsample_t: scale %d x %d too large", a.W, a.ws);
-  const int cvtot = a.C / vec;
-  a.cvw = 256 / a.ws;
-  if (a.cvw > cvtot) a.cvw = cvtot;
-  if (a.cvw < 1) a.cvw = 1;
-  a.chunks = (cvtot + a.cvw - 1) / a.cvw;
-  // ~16 full-resolution rows per band
-  a.rband = (16 * a.hs + a.H - 1) / a.H;
-  if (a.rband < 1) a.rband = 1;
-  a.bands = (a.hs + a.rband - 1) / a.rband;
-  const long long blocks = (long long)a.N * a.bands * a.chunks;
-  HR_REQUIRE(blocks < (1ll << 31), "upsample_t: grid");
-  if (op.i[0] == HR_F32)
-    hipLaunchKernelGGL(upsample_t_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(upsample_t_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], Cc = op.i[4], nout = op.i[5], align = op.i[6];
+  const int vec = dtype == HR_F32 ? 4 : 8;
+  HR_REQUIRE(dtype == HR_F32 || dtype == HR_BF16, "upsample_t: dtype");
+  HR_REQUIRE(op.p[0] && N > 0 && H > 0 && W > 0 && Cc > 0 && Cc % vec == 0 && nout >= 1 && nout <= 3, "upsample_t: args");
+  void* outs[3];
+  int hs[3], ws[3];
+  for (int k = 0; k < nout; ++k) {
+    outs[k] = op.p[1 + k]; hs[k] = op.i[7 + 2 * k]; ws[k] = op.i[8 + 2 * k];
+    HR_REQUIRE(outs[k] && hs[k] >= 1 && ws[k] >= 1 && hs[k] <= H && ws[k] <= W && ws[k] <= 256,
+               "upsample_t: output %d: %dx%d from %dx%d", k, hs[k], ws[k], H, W);
+  }
+  // integer scales 2 / 4 / 8 (the head): all outputs from ONE pass over G (head_mix.hip)
+  if (op.i[13] == 0 && hr_upsample_t_tile(dtype, op.p[0], outs, hs, ws, nout, N, H, W, Cc, align, s) == 0)
+    return hr_check_launch("upsample_t");
+  for (int k = 0; k < nout; ++k) {
+    UpTArgs a;
+    a.g = (const char*)op.p[0]; a.out = (char*)outs[k];
+    a.N = N; a.H = H; a.W = W; a.C = Cc; a.hs = hs[k]; a.ws = ws[k]; a.align = align;
+    HR_REQUIRE(2 * ((a.W + a.ws - 1) / a.ws) + 4 <= CATB_MAXW, "upsample_t: scale %d x %d too large", a.W, a.ws);
+    const int cvtot = a.C / vec;
+    a.cvw = 256 / a.ws;
+    if (a.cvw > cvtot) a.cvw = cvtot;
+    if (a.cvw < 1) a.cvw = 1;
+    a.chunks = (cvtot + a.cvw - 1) / a.cvw;
+    // ~16 full-resolution rows per band
+    a.rband = (16 * a.hs + a.H - 1) / a.H;
+    if (a.rband < 1) a.rband = 1;
+    a.bands = (a.hs + a.rband - 1) / a.rband;
+    const long long blocks = (long long)a.N * a.bands * a.chunks;
+    HR_REQUIRE(blocks < (1ll << 31), "upsample_t: grid");
+    if (dtype == HR_F32)
+      hipLaunchKernelGGL(upsample_t_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(upsample_t_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  }
   return hr_check_launch("upsample_t");
 }
 

@@ -29,21 +29,14 @@ struct GemmArgs {
   const float* bias;  // [N] or NULL
   char* y;            // [P][N] bf16
   float* sums;        // [8][2][N] f32 (atomic) or NULL
-  float* rows;        // [workgroups][2][N] f32: one statistics row per workgroup instead (deterministic) or NULL
   long long P;
   int K, N;
-  // MIX (the head without its concat, hrnet_head_mix): up to three lower-resolution [N][uh][uw][N] tensors whose
-  // bilinear upsampling to the H x W pixel grid of x is added to every output before the store and the statistics
-  const char* up[3];
-  int uh[3], uw[3];
-  int nup, H, W, align;
 };
 
 constexpr int G_BM = 128, G_BN = 512, G_BK = 32, G_NT = 512;
 constexpr int G_ROWB = G_BK * 2 + 16;              // padded LDS row: 80 bytes (conflict-free 16-byte operand reads)
 constexpr int G_XB = G_BM * G_ROWB, G_WB = G_BN * G_ROWB;
 
-template <bool MIX>
 __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
   typedef bf16_t T;
   __shared__ __attribute__((aligned(16))) char lds[2 * (G_XB + G_WB)];
@@ -115,7 +108,7 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
   }
 
   // ---- epilogue: bias, store (8 contiguous channels per lane and 32-channel group), statistics ----
-  const bool stats = a.sums != nullptr || a.rows != nullptr;
+  const bool stats = a.sums != nullptr;
   float* sl = (float*)lds;            // [2 pixel blocks][2][512] partial sums (the chunk buffers are free)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {       // 32-channel group j of this wave's 128 channels
@@ -134,31 +127,6 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
       v[4] = acc[2 * j + 1][g].x; v[5] = acc[2 * j + 1][g].y; v[6] = acc[2 * j + 1][g].z; v[7] = acc[2 * j + 1][g].w;
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] += b8[c];
-      if constexpr (MIX) {
-        if (p < a.P && n0 < a.N) {
-          const int ox = (int)(p % a.W), oy = (int)((p / a.W) % a.H), img = (int)(p / ((long long)a.W * a.H));
-          for (int u = 0; u < a.nup; ++u) {
-            // (the arithmetic of bilinear_cat_kernel: hy*(hx*f00 + lx*f01) + ly*(hx*f10 + lx*f11))
-            const int hs = a.uh[u], ws = a.uw[u];
-            int y0, y1, x0, x1;
-            float ly, lx;
-            bilin_src(oy, hs, a.H, a.align, y0, y1, ly);
-            bilin_src(ox, ws, a.W, a.align, x0, x1, lx);
-            const size_t base = (size_t)img * hs * ws;
-            const char* src = a.up[u] + (size_t)n0 * 2;
-            const V16 q00 = *(const V16*)(src + (base + (size_t)y0 * ws + x0) * a.N * 2);
-            const V16 q01 = *(const V16*)(src + (base + (size_t)y0 * ws + x1) * a.N * 2);
-            const V16 q10 = *(const V16*)(src + (base + (size_t)y1 * ws + x0) * a.N * 2);
-            const V16 q11 = *(const V16*)(src + (base + (size_t)y1 * ws + x1) * a.N * 2);
-            float f00[8], f01[8], f10[8], f11[8];
-            v16_unpack<T>(q00, f00); v16_unpack<T>(q01, f01); v16_unpack<T>(q10, f10); v16_unpack<T>(q11, f11);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-              v[c] += hy * (hx * f00[c] + lx * f01[c]) + ly * (hx * f10[c] + lx * f11[c]);
-          }
-        }
-      }
       if (p < a.P && n0 < a.N) {
         *(V16*)(a.y + ((size_t)p * a.N + n0) * 2) = v16_pack<T>(v);
         if (stats) {
@@ -189,11 +157,9 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
     __syncthreads();
     for (int o = tid; o < 2 * G_BN; o += G_NT) {
       const int which = o / G_BN, n = o % G_BN;
-      if (n < a.N) {
-        const float v = sl[(0 * 2 + which) * G_BN + n] + sl[(1 * 2 + which) * G_BN + n];
-        if (a.rows) a.rows[((size_t)blockIdx.x * 2 + which) * a.N + n] = v;
-        else atomicAdd(a.sums + ((size_t)(blockIdx.x & (HR_BN_COPIES - 1)) * 2 + which) * a.N + n, v);
-      }
+      if (n < a.N)
+        atomicAdd(a.sums + ((size_t)(blockIdx.x & (HR_BN_COPIES - 1)) * 2 + which) * a.N + n,
+                  sl[(0 * 2 + which) * G_BN + n] + sl[(1 * 2 + which) * G_BN + n]);
     }
   }
 }
@@ -209,51 +175,11 @@ int hr_gemm_pw_supported(int dtype, int Cin, int Cout) {
 int hr_gemm_pw(const void* x, const void* w, const float* bias, void* y, float* sums, long long pixels, int Cin,
                int Cout, hipStream_t s) {
   HR_REQUIRE(x && w && y && pixels > 0, "gemm_pw: null pointer / empty shape");
-  GemmArgs a = {};
+  GemmArgs a;
   a.x = (const char*)x; a.w = (const char*)w; a.bias = bias; a.y = (char*)y; a.sums = sums;
   a.P = pixels; a.K = Cin; a.N = Cout;
   const long long blocks = (pixels + G_BM - 1) / G_BM;
   HR_REQUIRE(blocks < (1ll << 31), "gemm_pw: pixel count");
-  hipLaunchKernelGGL(gemm_pw_kernel<false>, dim3((unsigned)blocks), dim3(G_NT), 0, s, a);
+  hipLaunchKernelGGL(gemm_pw_kernel, dim3((unsigned)blocks), dim3(G_NT), 0, s, a);
   return hr_check_launch("gemm_pw");
-}
-
-// ---- the head without its 480-channel concat (pose_hrnet.py:560-566) ----------------------------------------------
-//   last_layer.0( cat(x0, up(x1), up(x2), up(x3)) ) = W0 x0 + up(W1 x1) + up(W2 x2) + up(W3 x3) + b
-// (a 1x1 convolution commutes with bilinear upsampling): the three low-resolution products t_i = W_i x_i are plain
-// 1x1 conv launches at THEIR resolution, and this launch forms W0 x0 on the full-resolution grid (K = C0), adds the
-// bias and the bilinearly upsampled t_i in its epilogue, stores the raw 480-channel output once and gathers its batch
-// statistics: 1/8 of the FLOPs of the concat form, and neither the concat nor its gradient ever exist.
-// slots: i = {dtype, N, H, W, C0, Cout, nup, align, h1, w1, h2, w2, h3, w3, rows mode}
-//        p = {x0 [N][H][W][C0], w0 packed [Cout][C0], bias f32 [Cout] or NULL, y [N][H][W][Cout],
-//             statistics (i[14] = 0: sums[8][2][Cout], float atomics; 1: rows[hrnet_head_mix_rows()][2][Cout]) or NULL,
-//             t1, t2, t3 [N][h][w][Cout]}
-extern "C" int hrnet_head_mix_rows(int N, int H, int W) {
-  return (int)(((long long)N * H * W + G_BM - 1) / G_BM);
-}
-
-extern "C" int hrnet_head_mix_supported(int dtype, int C0, int Cout) {
-  return dtype == HR_BF16 && C0 % 32 == 0 && C0 >= 32 && Cout >= 16 && Cout <= G_BN && Cout % 8 == 0;
-}
-
-int hr_launch_head_mix(const HrOp& op, hipStream_t s) {
-  const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], C0 = op.i[4], Cout = op.i[5], nup = op.i[6];
-  HR_REQUIRE(hrnet_head_mix_supported(dtype, C0, Cout), "head_mix: bf16, C0 %% 32 == 0, Cout <= %d (got %d, %d, %d)",
-             G_BN, dtype, C0, Cout);
-  HR_REQUIRE(N > 0 && H > 0 && W > 0 && nup >= 0 && nup <= 3, "head_mix: shape");
-  HR_REQUIRE(op.p[0] && op.p[1] && op.p[3], "head_mix: null pointer");
-  GemmArgs a = {};
-  a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.y = (char*)op.p[3];
-  if (op.i[14]) a.rows = (float*)op.p[4]; else a.sums = (float*)op.p[4];
-  a.P = (long long)N * H * W; a.K = C0; a.N = Cout;
-  a.nup = nup; a.H = H; a.W = W; a.align = op.i[7];
-  for (int u = 0; u < nup; ++u) {
-    a.up[u] = (const char*)op.p[5 + u];
-    a.uh[u] = op.i[8 + 2 * u]; a.uw[u] = op.i[9 + 2 * u];
-    HR_REQUIRE(a.up[u] && a.uh[u] > 0 && a.uw[u] > 0, "head_mix: low-resolution term %d", u);
-  }
-  const long long blocks = (a.P + G_BM - 1) / G_BM;
-  HR_REQUIRE(blocks < (1ll << 31), "head_mix: pixel count");
-  hipLaunchKernelGGL(gemm_pw_kernel<true>, dim3((unsigned)blocks), dim3(G_NT), 0, s, a);
-  return hr_check_launch("head_mix");
 }

@@ -122,7 +122,7 @@ _SIGS = {
     'hrnet_head_mix': [_c_int] + [_c_vp] * 5 + [_c_int, _pp, _ip, _ip] + [_c_int] * 7 + [_c_vp],
     'hrnet_head_mix_rows': [_c_int] * 3,
     'hrnet_head_mix_supported': [_c_int] * 3,
-    'hrnet_upsample_bilinear_t': [_c_int, _c_vp, _c_vp] + [_c_int] * 7 + [_c_vp],
+    'hrnet_upsample_bilinear_t': [_c_int, _c_vp, _pp, _ip, _ip] + [_c_int] * 7 + [_c_vp],
     'hrnet_gaussian_targets': [_c_vp] * 3 + [_c_int] * 3 + [_c_float, _c_vp],
     'hrnet_normalize_u8': [_c_vp, _c_vp] + [_c_int] * 3 + [ctypes.POINTER(ctypes.c_float)] * 2 + [_c_vp],
     'hrnet_spatial_softmax_fwd': [_c_vp] * 3 + [_c_int] * 2 + [_c_vp],

@@ -404,6 +404,61 @@ class Plan(object):
         self._tape(('cat', list(vals), cat, align))
         return Val(cat)
 
+    def head_mix(self, vals, crec, bnrec, align=False):
+        """last_layer[0] over cat(x0, up(x1), ...) WITHOUT the concat (pose_hrnet.py:560-566; csrc/gemm_pw.hip):
+        t_j = W_j x_j at branch j's resolution, then y = W0 x0 + bias + sum_j up(t_j) with its batch statistics."""
+        net = self.net
+        x0 = vals[0].act
+        widths = [v.act.C for v in vals]
+        offs = [0]
+        for c in widths:
+            offs.append(offs[-1] + c)
+        wfs = net.head_slices(crec, widths)
+        y = self._act(crec.prefix, x0.N, x0.H, x0.W, crec.Cout_pad)
+        ts = []
+        for j in range(1, len(vals)):
+            xa = vals[j].act
+            t = self._act('{}.t{}'.format(crec.prefix, j), xa.N, xa.H, xa.W, crec.Cout_pad)
+            i = self.fwd.add(C.OP_CONV, ints=(self.dtid, xa.N, xa.H, xa.W, xa.C, xa.H, xa.W, crec.Cout_pad, 1, 1, 0,
+                                              0, 0, 0),
+                             ptrs=(C.ptr(xa.t), C.ptr(wfs[j]), None, None, None, C.ptr(t.t), None))
+            self.fwd.tags[i] = '{}.t{}'.format(crec.prefix, j)
+            ts.append(t)
+        want_stats = bnrec is not None and self.training
+        rows_mode = 0 if self.bn_sums else 1
+        ints = [self.dtid, x0.N, x0.H, x0.W, x0.C, crec.Cout_pad, len(ts), 1 if align else 0] + [0] * 6 + [rows_mode]
+        for k, t in enumerate(ts):
+            ints[8 + 2 * k], ints[9 + 2 * k] = t.H, t.W
+        bias = crec.mod.bias
+        i = self.fwd.add(C.OP_HEAD_MIX, ints=ints,
+                         ptrs=[C.ptr(x0.t), C.ptr(wfs[0]), C.ptr(net.bias_pad[crec.prefix]) if bias is not None else None,
+                               C.ptr(y.t), C.ptr(bnrec.sums) if (want_stats and self.bn_sums) else None]
+                         + [C.ptr(t.t) for t in ts])
+        self.fwd.tags[i] = crec.prefix
+        rows = C.call('hrnet_head_mix_rows', x0.N, x0.H, x0.W)
+        if want_stats and not self.bn_sums:
+            self.max_stats = max(self.max_stats, rows * 2 * crec.Cout_pad)
+            self._scratch(self.fwd, i, 4, 'stats')
+        for v in vals:
+            assert v.bn is None and not v.relu
+            v.act.nuse += 1
+        if bnrec is not None:
+            y.bn = bnrec
+            bnrec.count = float(y.pixels)
+            if self.training and self.bn_sums:
+                self.bn_finalize_list.append(bnrec)
+            elif self.training:
+                m = bnrec.mod
+                j = self.fwd.add(C.OP_BN_FINALIZE, ints=(rows, bnrec.C, 1),
+                                 floats=(y.pixels, m.momentum if m.momentum is not None else 0.1, m.eps),
+                                 ptrs=(None, C.ptr(m.weight), C.ptr(m.bias), C.ptr(m.running_mean),
+                                       C.ptr(m.running_var), C.ptr(m.num_batches_tracked), C.ptr(bnrec.scale),
+                                       C.ptr(bnrec.shift), C.ptr(bnrec.mean), C.ptr(bnrec.invstd)))
+                self._scratch(self.fwd, j, 0, 'stats')
+        self._tape(('headmix', list(vals), crec, y, bnrec, ts, offs, align))
+        self.n_head_mix = 1
+        return Val(y, bnrec, True)
+
     # ---- network walk (reference: PoseHighResolutionNet.forward, pose_hrnet.py:511-568) ----
     def _build(self):
         net = self.net
@@ -487,10 +542,23 @@ class Plan(object):
             if s == 3:
                 inter = ys[0]
         # pose_hrnet_softmax (lib/models/pose_hrnet_softmax.py:499-506): align_corners=True, inter_feat = the concat
-        cat = self.bilinear_cat(ys, 'head.cat', align=bool(getattr(net.module, 'head_align_corners', False)))
-        if getattr(net.module, 'inter_from_cat', False):
-            inter = cat
-        h = self.conv(cat, cv['last_layer.0'], 1, bn['last_layer.1'], relu=True)
+        # The head: last_layer[0] commutes with the bilinear upsampling, so (bf16, widths the mix launch takes) the
+        # 480-channel concat and its gradient are never formed - head_mix(). HRNET_HEAD_MIX=0, the fp32 device path
+        # and pose_hrnet_softmax (whose inter_feat IS the concat) keep the concat form.
+        align = bool(getattr(net.module, 'head_align_corners', False))
+        c0 = cv['last_layer.0']
+        self.n_head_mix = 0
+        mix = (os.environ.get('HRNET_HEAD_MIX', '1') != '0' and not getattr(net.module, 'inter_from_cat', False)
+               and 2 <= len(ys) <= 4 and all(v.bn is None and not v.relu for v in ys)
+               and sum(v.act.C for v in ys) == c0.Cin and c0.Cin_pad == c0.Cin and c0.Cout_pad == c0.Cout
+               and C.call('hrnet_head_mix_supported', self.dtid, ys[0].act.C, c0.Cout_pad) == 1)
+        if mix:
+            h = self.head_mix(ys, c0, bn['last_layer.1'], align=align)
+        else:
+            cat = self.bilinear_cat(ys, 'head.cat', align=align)
+            if getattr(net.module, 'inter_from_cat', False):
+                inter = cat
+            h = self.conv(cat, c0, 1, bn['last_layer.1'], relu=True)
         out = self.conv(h, cv['last_layer.3'], 1, None, relu=False)
         self.out_act, self.inter_act = out.act, inter.act
         self.nj = cv['last_layer.3'].Cout
@@ -717,7 +785,7 @@ class Plan(object):
             elif e[0] == 'sum':
                 ins = [t.act for t in e[1]]
                 producer_sum[id(e[4])] = e
-            elif e[0] == 'cat':
+            elif e[0] in ('cat', 'headmix'):
                 ins = [v.act for v in e[1]]
             else:
                 continue
@@ -833,6 +901,8 @@ class Plan(object):
                              ptrs=[C.ptr(cat.g)] + [C.ptr(v.act.g) for v in vals])
                 for v in vals:
                     v.act.ginit = True
+            elif e[0] == 'headmix':
+                self._head_mix_backward(e, lane, in_region, relu_of)
             elif e[0] == 'sum':
                 _, terms, shifts, relu_out, out = e
                 if out is self.inter_act and self.inter_gop is None:
@@ -1012,6 +1082,79 @@ class Plan(object):
             if late:
                 self.bwd.join(late)       # the deferred / offloaded weight gradients (and their slab sums) are done
             self._upload_wred_tables()
+
+    # ---- backward of the head without its concat (head_mix) ----
+    def _head_mix_backward(self, e, lane, in_region, relu_of):
+        """G = d(raw y) (BatchNorm backward in place); g_j = up^T(G) at branch j's resolution (hrnet_upsample_bilinear_t);
+        dW[:, slice j] = g_j^T x_j and dx_j = W_j^T g_j as 1x1 launches at branch resolution (g_0 = G, full resolution
+        with K = C0): autograd of pose_hrnet.py:560-566, an eighth of the concat form's FLOPs"""
+        _, vals, crec, y, bnrec, ts, offs, align = e
+        net = self.net
+        self.bwd.tags[len(self.bwd)] = crec.prefix
+        if not y.ginit:
+            raise RuntimeError('no gradient reaches ' + y.name)
+        if bnrec is not None and not y.bn_done:
+            self._bn_backward(y, C.ptr(y.g), None, 0, relu_of.get(id(y), False))
+        w = crec.mod.weight
+        if crec.mod.bias is not None and not (bnrec is not None and self.training):
+            blocks = C.call('hrnet_reduce_blocks', 1, 1, y.pixels, y.C)
+            self.max_bwd_part = max(self.max_bwd_part, blocks * y.C)
+            i = self.bwd.add(C.OP_BIAS_GRAD, ints=(self.dtid, y.pixels, y.C, crec.Cout, 1),
+                             ptrs=(C.ptr(y.g), C.ptr(net.grad_of(crec.mod.bias)), None))
+            self._scratch(self.bwd, i, 2, 'bwdpart')
+        if ts:
+            ints = [self.dtid, y.N, y.H, y.W, y.C, len(ts), 1 if align else 0]
+            for t in ts:
+                ints += [t.H, t.W]
+                t.ginit = True
+            self.bwd.add(C.OP_UPSAMPLE_T, ints=ints, ptrs=[C.ptr(y.g)] + [C.ptr(t.g) for t in ts])
+        gw = net.grad_of(w)
+        direct = self.batch_wred and self.wgrad_atomic
+        for j, v in enumerate(vals):
+            x = v.act
+            dy = y.g if j == 0 else ts[j - 1].g
+            cj = offs[j + 1] - offs[j]
+            gptr = gw.data_ptr() + 4 * offs[j]
+            # ---- weight gradient of the column slice (rows crec.Cin floats apart)
+            nsplit = C.call('hrnet_wgrad_splits', self.dtid, x.N, x.H, x.W, y.C, x.C, 1, 1)
+            wints = [self.dtid, x.N, x.H, x.W, x.C, x.H, x.W, y.C, 1, 1, 0, nsplit, 1 if direct else 0, crec.Cout, cj,
+                     crec.Cin if direct else 0]
+            wptrs = [C.ptr(x.t), C.ptr(dy), None, None, None]
+            side = None
+            if self.offload_wgrad and lane == 0 and not in_region:
+                side = 1 + self._offload_rr % max(1, self.nlanes - 1)
+                self._offload_rr += 1
+                self.bwd.sync(0, side)
+                self._offload_lanes.add(side)
+            if direct:
+                wptrs[4] = gptr
+                self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=side)
+            elif self.batch_wred:
+                slabs = self._f32(nsplit * y.C * x.C)
+                self.slab_bytes += slabs.numel() * 4
+                wptrs[4] = C.ptr(slabs)
+                ent = dict(slabs=C.ptr(slabs), grad=gptr, nsplit=nsplit, Cout_pad=y.C, Cin_pad=x.C, ks=1,
+                           Cout=crec.Cout, Cin=cj, kflat=0, accumulate=1, ld=crec.Cin)
+                self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=side)
+                self._wred.setdefault(side if side is not None else self.bwd.lane, []).append(ent)
+            else:
+                self.max_slab = max(self.max_slab, nsplit * y.C * x.C)
+                i = self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs)
+                self._scratch(self.bwd, i, 4, 'slab')
+                i = self.bwd.add(C.OP_WGRAD_REDUCE, ints=(nsplit, y.C, x.C, 1, crec.Cout, cj, 0, 1, crec.Cin),
+                                 ptrs=(None, gptr))
+                self._scratch(self.bwd, i, 0, 'slab')
+            if side is None and lane == 0:
+                self._wred_bytes += crec.Cout * cj * 4
+            # ---- input gradient: rows offs[j] .. offs[j+1] of the transposed packed weight ([Cin][Cout_pad])
+            if x.g is not None:
+                wd = crec.wd.data_ptr() + offs[j] * crec.Cout_pad * self.esize
+                self.bwd.add(C.OP_CONV,
+                             ints=(self.dtid, x.N, x.H, x.W, y.C, x.H, x.W, x.C, 1, 1, 0, 0, 1 if x.ginit else 0, 0, 0),
+                             ptrs=[C.ptr(dy), wd, None, None, None, C.ptr(x.g), None, None, None, None, None])
+                x.ginit = True
+        if lane == 0 and not in_region:
+            self._bucket_mark_after_conv(crec)
 
     # ---- fused backward of a BasicBlock (conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU: pose_hrnet.py:41-57) ----
     def _find_fused_blocks(self):

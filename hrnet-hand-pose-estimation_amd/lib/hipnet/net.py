@@ -102,15 +102,22 @@ class HipNet(object):
         import ctypes
         ents = (C.HrPackEnt * len(items))()
         block = 0
-        for e, (r, mode, out) in zip(ents, items):
+        for e, item in zip(ents, items):
+            r, mode, out = item[:3]
             taps = r.ks * r.ks
             if (mode == 1 and r.Cout_pad * (taps + 1) > 4864) or (mode == 0 and r.Cin * taps > 4864):
                 raise ValueError('{}: {} output channels at {}x{} exceed the LDS staging of the weight packer'.format(
                     r.prefix, r.Cout, r.ks, r.ks))
             e.w, e.out = C.ptr(r.mod.weight), C.ptr(out)
             e.Cout, e.Cin, e.ks, e.Cout_pad, e.Cin_pad, e.mode = r.Cout, r.Cin, r.ks, r.Cout_pad, r.Cin_pad, mode
+            if len(item) > 3:
+                # a column slice [c0, c0 + c) of a 1x1 weight: rows r.Cin floats apart
+                c0, c = item[3], item[4]
+                assert r.ks == 1 and mode == 0
+                e.w = r.mod.weight.data_ptr() + 4 * c0
+                e.Cin, e.Cin_pad, e.ld = c, c, r.Cin
             e.block0 = block
-            block += C.call('hrnet_pack_blocks', r.Cout_pad, r.Cin_pad, r.ks, mode)
+            block += C.call('hrnet_pack_blocks', e.Cout_pad, e.Cin_pad, r.ks, mode)
         raw = bytes(ctypes.string_at(ctypes.addressof(ents), ctypes.sizeof(ents)))
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._tables = getattr(self, '_tables', []) + [table]
@@ -118,10 +125,30 @@ class HipNet(object):
         prog.add(C.OP_PACK_TABLE, ints=(self.dtid, len(items), block), ptrs=(C.ptr(table),))
         return prog.finalize()
 
+    def head_slices(self, crec, widths):
+        """forward-layout copies [Cout][C_j] of the column slices W[:, c_j : c_j + C_j] of a 1x1 weight (the head
+        without its concat, engine.Plan.head_mix): packed by one more table launch whenever the weights are"""
+        key = (crec.prefix, tuple(widths))
+        if getattr(self, '_head_key', None) != key:
+            es = torch.empty((), dtype=self.compute_dtype).element_size()
+            items, off = [], 0
+            self._head_wf = []
+            for c in widths:
+                out = torch.empty(crec.Cout_pad * c * es, dtype=torch.uint8, device=self.device)
+                self._head_wf.append(out)
+                items.append((crec, 0, out, off, c))
+                off += c
+            self._head_pack = self._pack_program(items)
+            self._head_key = key
+            self._head_pack.run()
+        return self._head_wf
+
     def pack_weights(self, for_backward):
         """master f32 OIHW -> kernel layouts (forward always, transposed dgrad copy on demand)"""
         if not self.fwd_packed:
             self.pack_f.run()
+            if getattr(self, '_head_pack', None) is not None:
+                self._head_pack.run()
             for name, buf in self.bias_pad.items():
                 b = self.convs[name].mod.bias
                 buf[:b.numel()].copy_(b.detach())

@@ -75,7 +75,8 @@ enum {
                               i[2] = kind of the jobs, i[3] = dtype */
   HR_OP_HEAD_MIX = 26,     /* hrnet_head_mix: i = {dtype, N, H, W, C0, Cout, nup, align, h1, w1, h2, w2, h3, w3, rows
                               mode}, p = {x0, w0 packed, bias, y, statistics, t1, t2, t3} */
-  HR_OP_UPSAMPLE_T = 27    /* hrnet_upsample_bilinear_t: i = {dtype, N, H, W, C, hs, ws, align}, p = {G, out} */
+  HR_OP_UPSAMPLE_T = 27    /* hrnet_upsample_bilinear_t: i = {dtype, N, H, W, C, nout, align, h1, w1, h2, w2, h3, w3,
+                              streamed}, p = {G, out1, out2, out3} */
 };
 
 /* One recorded op: integer / float / pointer slots, meaning per kind (see the
@@ -434,17 +435,19 @@ int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const 
  * upsampling of t_1..t_nup (align_corners as hrnet_bilinear_cat), stores y once and gathers its batch statistics:
  *   rows_mode 0: stats = sums[8][2][Cout] (float atomics, as hrnet_conv2d with stats_atomic)
  *   rows_mode 1: stats = rows[hrnet_head_mix_rows(N,H,W)][2][Cout], one row per workgroup (deterministic)
- * bf16, C0 a multiple of 32, Cout <= 512 (hrnet_head_mix_supported). w0: hrnet_pack_weights layout [Cout][C0].
+ * bf16 (MFMA; C0 a multiple of 32) or f32 (plain FMAs: the validation path), Cout <= 512 (hrnet_head_mix_supported).
+ * w0: hrnet_pack_weights layout [Cout][C0].
  */
 int hrnet_head_mix(int dtype, const void* x0, const void* w0, const float* bias, void* y, float* stats, int rows_mode,
                    const void* const* ts, const int* hs, const int* ws, int nup, int N, int H, int W, int C0, int Cout,
                    int align_corners, hr_stream_t stream);
 int hrnet_head_mix_rows(int N, int H, int W);
 int hrnet_head_mix_supported(int dtype, int C0, int Cout);
-/* out[N,hs,ws,C] = bilinear^T(G[N,H,W,C]) over ALL channels: the gradient of t_j above (autograd of F.upsample,
- * pose_hrnet.py:561-563). Separable, streamed over the rows of G; deterministic. */
-int hrnet_upsample_bilinear_t(int dtype, const void* g, void* out, int N, int H, int W, int C, int hs, int ws,
-                              int align_corners, hr_stream_t stream);
+/* outs[k][N,hs[k],ws[k],C] = bilinear^T(G[N,H,W,C]) over ALL channels, k < nout <= 3: the gradients of t_j above
+ * (autograd of F.upsample, pose_hrnet.py:561-563). Deterministic. Integer scales 2 / 4 / 8 with align_corners=0 take
+ * ONE pass over G for all outputs (LDS-staged tiles); anything else (or streamed=1) a separable streamed walk per output. */
+int hrnet_upsample_bilinear_t(int dtype, const void* g, void* const* outs, const int* hs, const int* ws, int nout,
+                              int N, int H, int W, int C, int align_corners, int streamed, hr_stream_t stream);
 
 /* stem: NCHW f32 image -> im2col rows [N,Ho,Wo,Kpad] (k = (r*3+s)*C + c), 3x3 stride 2 pad 1
  * (conv1, pose_hrnet.py:283-284,512). */

@@ -289,6 +289,10 @@ def _written(op, C):
         return [(op.p[0], True)] + ([(op.p[7], True)] if op.p[7] else [])
     if k == C.OP_BILINEAR_CAT_BWD:
         return [(op.p[1 + j], True) for j in range(op.i[1])]
+    if k == C.OP_HEAD_MIX:
+        return [(op.p[3], True)]          # the head's raw output (its statistics feed a finalize launch)
+    if k == C.OP_UPSAMPLE_T:
+        return [(op.p[1], True)]
     if k == C.OP_BN_FINALIZE:
         return [(op.p[6], False), (op.p[7], False), (op.p[8], False), (op.p[9], False)]
     if k == C.OP_BN_BWD_FINALIZE:
@@ -344,6 +348,7 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
         plans[name], outs[name] = p, (hm, inter, dt, net)
     p32, p16 = plans['32'], plans['16']
     assert (p32.n_fused_blocks > 0) == (fused != 'unfused') and p32.n_fused_blocks == p16.n_fused_blocks
+    assert p32.n_head_mix == 1 and p16.n_head_mix == 1      # the head without its concat, in both dtypes
     a32, k32 = _ptr_maps(p32, torch.float32)
     a16, k16 = _ptr_maps(p16, torch.bfloat16)
 

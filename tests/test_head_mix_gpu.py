@@ -37,7 +37,7 @@ def _ip(vals):
     return (ctypes.c_int * max(1, len(vals)))(*vals)
 
 
-def _pack_slice(w, c0, c1):
+def _pack_slice(w, c0, c1, DT=DT):
     """forward layout [Cout][c1-c0] of the column slice, through the table packer's row pitch"""
     hh, C = _h(), _C()
     co, ci = w.shape[0], w.shape[1]
@@ -50,7 +50,7 @@ def _pack_slice(w, c0, c1):
     blocks = C.call('hrnet_pack_blocks', co, c1 - c0, 1, 0)
     raw = bytes(ctypes.string_at(ctypes.addressof(ent), ctypes.sizeof(ent)))
     table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(hh.DEV)
-    C.call('hrnet_pack_weights_table', 1, table.data_ptr(), 1, blocks, C.stream_ptr())
+    C.call('hrnet_pack_weights_table', C.dtype_id(DT), table.data_ptr(), 1, blocks, C.stream_ptr())
     hh.sync()
     return out
 
@@ -65,11 +65,13 @@ MIX_CASES = [
 ]
 
 
+@pytest.mark.parametrize('DT', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('rows_mode', [0, 1])
 @pytest.mark.parametrize('case', MIX_CASES)
-def test_head_mix_equals_upsample_cat_conv(case, rows_mode):
+def test_head_mix_equals_upsample_cat_conv(case, rows_mode, DT):
     hh, C = _h(), _C()
     N, H, W, cs, Cout, align = case
+    f32 = DT == torch.float32
     g = torch.Generator().manual_seed(11 + H + Cout + len(cs))
     xs = [torch.randn(N, c, H >> j, W >> j, generator=g) for j, c in enumerate(cs)]
     xs = [x.to(DT).float() for x in xs]                                   # the values the device tensors hold
@@ -84,23 +86,24 @@ def test_head_mix_equals_upsample_cat_conv(case, rows_mode):
     xd = [hh.nhwc(x, DT) for x in xs]
     ts = []
     for j in range(1, len(cs)):
-        wj = _pack_slice(w, int(offs[j]), int(offs[j + 1]))
+        wj = _pack_slice(w, int(offs[j]), int(offs[j + 1]), DT)
         t, _ = hh.conv2d(xd[j], wj, N, H >> j, W >> j, cs[j], Cout, 1, 1, DT)
         ts.append(t)
-    w0 = _pack_slice(w, 0, cs[0])
+    w0 = _pack_slice(w, 0, cs[0], DT)
     y = torch.full((N, H, W, Cout), float('nan'), dtype=DT, device=hh.DEV)
     nrows = C.call('hrnet_head_mix_rows', N, H, W)
     stats = torch.zeros((nrows if rows_mode else 8), 2, Cout, dtype=torch.float32, device=hh.DEV)
     bd = bias.to(hh.DEV)
-    assert C.call('hrnet_head_mix_supported', 1, cs[0], Cout) == 1
-    C.call('hrnet_head_mix', 1, xd[0].data_ptr(), w0.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), rows_mode,
+    assert C.call('hrnet_head_mix_supported', C.dtype_id(DT), cs[0], Cout) == 1
+    C.call('hrnet_head_mix', C.dtype_id(DT), xd[0].data_ptr(), w0.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), rows_mode,
            _pp(ts), _ip([H >> j for j in range(1, len(cs))]), _ip([W >> j for j in range(1, len(cs))]), len(ts),
            N, H, W, cs[0], Cout, 1 if align else 0, C.stream_ptr())
     hh.sync()
     got = hh.from_nhwc(y)
     scale = float(ref.abs().max())
-    # two bf16 roundings on the way (t_j, y): 2^-8 each, relative to the magnitudes involved
-    assert float((got - ref).abs().max()) <= 1.2e-2 * scale, (float((got - ref).abs().max()), scale)
+    # bf16: two roundings on the way (t_j, y), 2^-8 each, relative to the magnitudes involved; f32: summation order
+    tol = 2e-5 if f32 else 1.2e-2
+    assert float((got - ref).abs().max()) <= tol * scale, (float((got - ref).abs().max()), scale)
     # the statistics are those of the f32 values the kernel formed (before the bf16 store)
     s = stats.sum(0).cpu()
     cnt = N * H * W
@@ -128,35 +131,41 @@ def test_head_mix_rows_are_reproducible():
 
 
 UPT_CASES = [
-    # N, H, W, C, hs, ws, align
-    (2, 64, 64, 480, 32, 32, False),
-    (2, 64, 64, 480, 16, 16, False),
-    (2, 64, 64, 480, 8, 8, False),
-    (1, 32, 48, 64, 8, 12, False),        # non-square, scale 4
-    (1, 24, 24, 40, 9, 9, False),         # non-integer scale (8/3): clamped taps at both borders
-    (2, 32, 32, 96, 16, 16, True),        # align_corners=True
-    (1, 16, 16, 32, 16, 16, False),       # same size: identity
+    # N, H, W, C, output sizes, align
+    (2, 64, 64, 480, [(32, 32)], False),
+    (2, 64, 64, 480, [(16, 16)], False),
+    (2, 64, 64, 480, [(8, 8)], False),
+    (2, 64, 64, 480, [(32, 32), (16, 16), (8, 8)], False),     # the head: three scales, one pass over G (tile form)
+    (1, 48, 40, 72, [(24, 20), (12, 10), (6, 5)], False),      # w48-like maps: tiles that overhang the image
+    (1, 32, 48, 64, [(8, 12)], False),        # non-square, scale 4
+    (1, 24, 24, 40, [(9, 9)], False),         # non-integer scale (8/3): streamed form, clamped taps at both borders
+    (2, 32, 32, 96, [(16, 16)], True),        # align_corners=True: streamed form
+    (1, 16, 16, 32, [(16, 16)], False),       # same size: identity (streamed form)
 ]
 
 
+@pytest.mark.parametrize('streamed', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('case', UPT_CASES)
-def test_upsample_transpose_equals_autograd_of_interpolate(case, dtype):
+def test_upsample_transpose_equals_autograd_of_interpolate(case, dtype, streamed):
     hh, C = _h(), _C()
-    N, H, W, Cc, hs, ws, align = case
-    g = torch.Generator().manual_seed(3 + H + hs + Cc)
+    N, H, W, Cc, sizes, align = case
+    g = torch.Generator().manual_seed(3 + H + sizes[0][0] + Cc)
     G = torch.randn(N, Cc, H, W, generator=g).to(dtype).float()
-    x = torch.zeros(N, Cc, hs, ws, requires_grad=True)
-    F.interpolate(x, size=(H, W), mode='bilinear', align_corners=align).backward(G)
-    ref = x.grad
+    refs = []
+    for hs, ws in sizes:
+        x = torch.zeros(N, Cc, hs, ws, requires_grad=True)
+        F.interpolate(x, size=(H, W), mode='bilinear', align_corners=align).backward(G)
+        refs.append(x.grad)
     gd = hh.nhwc(G, dtype)
-    out = torch.full((N, hs, ws, Cc), float('nan'), dtype=dtype, device=hh.DEV)
-    C.call('hrnet_upsample_bilinear_t', C.dtype_id(dtype), gd.data_ptr(), out.data_ptr(), N, H, W, Cc, hs, ws,
-           1 if align else 0, C.stream_ptr())
+    outs = [torch.full((N, hs, ws, Cc), float('nan'), dtype=dtype, device=hh.DEV) for hs, ws in sizes]
+    C.call('hrnet_upsample_bilinear_t', C.dtype_id(dtype), gd.data_ptr(), _pp(outs), _ip([h for h, _ in sizes]),
+           _ip([w for _, w in sizes]), len(sizes), N, H, W, Cc, 1 if align else 0, streamed, C.stream_ptr())
     hh.sync()
-    got = hh.from_nhwc(out)
-    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2e-6) * float(ref.abs().max())
-    assert float((got - ref).abs().max()) <= tol, (float((got - ref).abs().max()), float(ref.abs().max()))
+    for out, ref in zip(outs, refs):
+        got = hh.from_nhwc(out)
+        tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2e-6) * float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= tol, (float((got - ref).abs().max()), float(ref.abs().max()))
 
 
 @pytest.mark.parametrize('atomic', [1, 0])
