@@ -109,10 +109,11 @@ constexpr int SUM_MAXC = 384;
 
 // SUMS: some term's BatchNorm comes as batch sums (training forward); the plain instantiation (eval forward,
 // deterministic training) carries neither the table nor the per-term test in its inner loop
+// (block `block0` of `nblocks`: a launch of its own, or one job of a table-driven launch)
 template <typename T, bool SUMS>
-__global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
+__device__ __forceinline__ void sum_terms_block(const SumArgs& a, int block0, int nblocks,
+                                                float (*tab)[2][SUMS ? SUM_MAXC : 1]) {
   constexpr int VEC = TT<T>::VEC;
-  __shared__ float tab[SUMS ? 4 : 1][2][SUMS ? SUM_MAXC : 1];
   if (SUMS && a.sums_mode) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
   }
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.Ho * a.Wo * cv;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = (long long)block0 * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)nblocks * blockDim.x) {
     const int v = (int)(idx % cv);
     long long pix = idx / cv;
     const int ox = (int)(pix % a.Wo);
@@ -169,6 +170,28 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
       for (int j = 0; j < VEC; ++j) accv[j] = fmaxf(accv[j], 0.f);
     }
     *(V16*)(a.out + (size_t)idx * 16) = v16_pack<T>(accv);
+  }
+}
+
+template <typename T, bool SUMS>
+__global__ __launch_bounds__(256) void sum_terms_kernel(SumArgs a) {
+  __shared__ float tab[SUMS ? 4 : 1][2][SUMS ? SUM_MAXC : 1];
+  sum_terms_block<T, SUMS>(a, (int)blockIdx.x, (int)gridDim.x, tab);
+}
+
+// slots of a HR_OP_SUM_TERMS op -> SumArgs (host: hr_launch_sum_terms; device: the table-driven launch)
+__host__ __device__ inline void sum_args_from_op(const HrOp& op, SumArgs& a) {
+  a.N = op.i[1]; a.Ho = op.i[2]; a.Wo = op.i[3]; a.C = op.i[4]; a.nterms = op.i[5]; a.relu_out = op.i[6];
+  a.out = (char*)op.p[0];
+  a.sums_mode = op.i[15];
+  for (int t = 0; t < 4; ++t) a.inv_count[t] = op.f[t];
+  a.eps = __builtin_bit_cast(float, op.i[16]);
+  for (int t = 0; t < 4; ++t) {
+    a.sh[t] = op.i[7 + t];
+    a.relu[t] = op.i[11 + t];
+    a.src[t] = (const char*)op.p[1 + t];
+    a.scale[t] = (const float*)op.p[5 + t];
+    a.shift[t] = (const float*)op.p[9 + t];
   }
 }
 
@@ -460,6 +483,18 @@ __global__ __launch_bounds__(256) void grad_term_table_kernel(const HrOp* tab, i
   const HrOp& op = ew_table_find(tab, n, local);
   const GradArgs a = ew_grad_args(op, false);
   grad_term_block<T>(a, local, op.i[17]);
+}
+
+// the forward sums of a HighResolutionModule's outputs (one per branch) as ONE launch: no fork / join around them
+template <typename T, bool SUMS>
+__global__ __launch_bounds__(256) void sum_terms_table_kernel(const HrOp* tab, int n) {
+  __shared__ float bn[SUMS ? 4 : 1][2][SUMS ? SUM_MAXC : 1];
+  int local;
+  const HrOp& op = ew_table_find(tab, n, local);
+  SumArgs a;
+  sum_args_from_op(op, a);
+  a.eps = __builtin_bit_cast(float, op.i[18]);      // (a table job: i[16] / i[17] hold its block range, eps moved to i[18])
+  sum_terms_block<T, SUMS>(a, local, op.i[17], bn);
 }
 
 template <typename T>
@@ -1091,21 +1126,12 @@ int hr_launch_bn_finalize(const HrOp& op, hipStream_t s) {
 int hr_launch_sum_terms(const HrOp& op, hipStream_t s) {
   SumArgs a;
   const int dtype = op.i[0];
-  a.N = op.i[1]; a.Ho = op.i[2]; a.Wo = op.i[3]; a.C = op.i[4]; a.nterms = op.i[5]; a.relu_out = op.i[6];
+  sum_args_from_op(op, a);
   HR_REQUIRE(a.nterms >= 1 && a.nterms <= 4, "sum_terms: nterms=%d", a.nterms);
   HR_REQUIRE(a.C % (dtype == HR_F32 ? 4 : 8) == 0, "sum_terms: C=%d", a.C);
-  a.out = (char*)op.p[0];
   HR_REQUIRE(a.out, "sum_terms: null out");
-  a.sums_mode = op.i[15];
-  for (int t = 0; t < 4; ++t) a.inv_count[t] = op.f[t];
-  a.eps = __builtin_bit_cast(float, op.i[16]);
   HR_REQUIRE(!a.sums_mode || a.C <= SUM_MAXC, "sum_terms: C=%d too wide for batch-sum terms", a.C);
   for (int t = 0; t < 4; ++t) {
-    a.sh[t] = op.i[7 + t];
-    a.relu[t] = op.i[11 + t];
-    a.src[t] = (const char*)op.p[1 + t];
-    a.scale[t] = (const float*)op.p[5 + t];
-    a.shift[t] = (const float*)op.p[9 + t];
     if (t < a.nterms) {
       HR_REQUIRE(a.src[t], "sum_terms: null src %d", t);
       HR_REQUIRE((a.Ho % (1 << a.sh[t])) == 0 && (a.Wo % (1 << a.sh[t])) == 0, "sum_terms: upsample shift");
@@ -1206,6 +1232,7 @@ extern "C" int hrnet_ew_table_blocks(int kind, int dtype, int N, int H, int W, i
   if (kind == HR_OP_GRAD_TERM) return (int)ew_grid((long long)N * H * W * (C / vec));
   if (kind == HR_OP_BN_BWD_REDUCE) return hrnet_reduce_blocks(N, H, W, C);
   if (kind == HR_OP_BN_BWD_FINALIZE) return (C + 31) / 32;
+  if (kind == HR_OP_SUM_TERMS) return (int)ew_grid((long long)N * H * W * (C / vec));      // (output size)
   return 0;
 }
 
@@ -1222,6 +1249,16 @@ int hr_launch_ew_table(const HrOp& op, hipStream_t s) {
     else hipLaunchKernelGGL(bn_bwd_reduce_table_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
   } else if (kind == HR_OP_BN_BWD_FINALIZE) {
     hipLaunchKernelGGL(bn_bwd_finalize_table_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, tab, n);
+  } else if (kind == HR_OP_SUM_TERMS) {
+    // op.i[4] != 0: some job's BatchNorm comes as batch sums (the instantiation with the coefficient table)
+    const bool sums = op.i[4] != 0;
+    if (dtype == HR_F32) {
+      if (sums) hipLaunchKernelGGL((sum_terms_table_kernel<float, true>), dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+      else hipLaunchKernelGGL((sum_terms_table_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+    } else {
+      if (sums) hipLaunchKernelGGL((sum_terms_table_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+      else hipLaunchKernelGGL((sum_terms_table_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+    }
   } else {
     HR_REQUIRE(false, "ew_table: kind %d cannot be batched", kind);
   }

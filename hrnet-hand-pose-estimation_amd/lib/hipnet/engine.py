@@ -338,7 +338,9 @@ class Plan(object):
         self._tape(('conv', xin, crec, stride, y, bnrec))
         return Val(y, bnrec, relu)
 
-    def sum(self, terms, shifts, relu_out, name):
+    def sum(self, terms, shifts, relu_out, name, batch=None):
+        """batch: a list - the op is appended to it as a job of a table-driven launch (HR_OP_EW_TABLE) instead of
+        being emitted as a launch of its own"""
         t0 = terms[0].act
         sh0 = shifts[0]
         out = self._act(name, t0.N, t0.H << sh0, t0.W << sh0, t0.C)
@@ -352,11 +354,22 @@ class Plan(object):
         bn_terms = [t for t in terms if t.bn is not None]
         hold = (self.fuse_sums and len(terms) == 2 and list(shifts) == [0, 0] and relu_out and len(bn_terms) == 1
                 and not bn_terms[0].relu and all(t.bn is not None or not t.relu for t in terms)
-                and (not self.bn_sums or t0.C <= 768))
+                and (not self.bn_sums or t0.C <= 768) and batch is None)
         emit = self.fwd.add
         if hold:
             held = []
             emit = lambda *a, **k: held.append((a, k))
+        elif batch is not None:
+            def emit(kind, ints=(), floats=(), ptrs=()):
+                op = C.HrOp()
+                op.kind = kind
+                for k, v in enumerate(ints):
+                    op.i[k] = int(v)
+                for k, v in enumerate(floats):
+                    op.f[k] = float(v)
+                for k, v in enumerate(ptrs):
+                    op.p[k] = v
+                batch.append(op)
         if self.bn_sums and any(t.bn for t in terms):
             import struct
             mode = sum(1 << k for k, t in enumerate(terms) if t.bn)
@@ -472,6 +485,7 @@ class Plan(object):
         self.fuse_sums = self.training and os.environ.get('HRNET_FUSE_SUM', '1') != '0'
         self._pending_sum = None
         self.n_fused_sums = 0
+        self.n_batched_fwd_sums = 0
         self.fwd.before_add = self._flush_pending_sum
         # Consumer-side BatchNorm (training): producers add their batch sums into 8 partial copies per BatchNorm with
         # float atomics, forward consumers build scale/shift from them on the fly, and ONE table-driven launch at the
@@ -646,22 +660,46 @@ class Plan(object):
         # backward pass that spreads a module's 16 sum-term passes over the lanes, and every consumer of a
         # branch gradient sits on that branch's lane
         sum_lanes = side and fuse_lanes and os.environ.get('HRNET_SUM_LANES', '1') != '0'
+        # ... or, forward (HRNET_BATCH_SUMFWD, default on): the nb sums as ONE table-driven launch on lane 0 - they are
+        # 10-30 us each, and the fork / join around them cost more than running them side by side saved. The tape
+        # keeps the ('fork' / 'join', side, 'sums') markers: the backward pass batches its side of them the same way.
+        batch = [] if (sum_lanes and os.environ.get('HRNET_BATCH_SUMFWD', '1') != '0') else None
         if sum_lanes:
-            self.fwd.fork(side)
+            if batch is None:
+                self.fwd.fork(side)
             self._tape(('fork', side, 'sums'))
         outs = []
         for i in range(nb):
-            if sum_lanes:
+            if sum_lanes and batch is None:
                 self.fwd.lane = i if i in side else 0
             terms = [term_of[(i, j)][0] for j in range(nb)]
             shifts = [term_of[(i, j)][1] for j in range(nb)]
             # the output-resolution term first (sum_terms sizes the output from term 0)
             order = sorted(range(nb), key=lambda q: shifts[q])
             outs.append(self.sum([terms[q] for q in order], [shifts[q] for q in order], True,
-                                 '{}.fuse.{}'.format(pre, i)))
+                                 '{}.fuse.{}'.format(pre, i), batch=batch))
+            if batch is not None:
+                self.tape_lanes[-1] = i if i in side else 0      # (the lane the backward pass works this branch on)
         self.fwd.lane = 0
+        if batch:
+            block, sums_mode = 0, 0
+            for op in batch:
+                nb_ = C.call('hrnet_ew_table_blocks', C.OP_SUM_TERMS, self.dtid, op.i[1], op.i[2], op.i[3], op.i[4])
+                # (slots of a table job: i[16] = first block, i[17] = blocks; the eps of HR_OP_SUM_TERMS moves to i[18])
+                op.i[18] = op.i[16]
+                op.i[16], op.i[17] = block, nb_
+                block += nb_
+                sums_mode |= op.i[15]
+            arr = (C.HrOp * len(batch))(*batch)
+            raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self.keep.append(table)
+            self.fwd.add(C.OP_EW_TABLE, ints=(len(batch), block, C.OP_SUM_TERMS, self.dtid, 1 if sums_mode else 0),
+                         ptrs=(C.ptr(table),))
+            self.n_batched_fwd_sums += len(batch)
         if sum_lanes:
-            self.fwd.join(side)
+            if batch is None:
+                self.fwd.join(side)
             self._tape(('join', side, 'sums'))
         return outs
 

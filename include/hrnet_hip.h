@@ -69,7 +69,9 @@ enum {
   HR_OP_BN_FINALIZE_TABLE = 22, /* p[0] = device HrBnEnt table, i[0] = n, i[1] = total blocks */
   HR_OP_BWD_PW = 23,       /* hrnet_conv1x1_bwd_fused (slots as HR_OP_BWD_FUSED) */
   HR_OP_CONV_SUM = 24,     /* hrnet_conv2d_sum */
-  HR_OP_EW_TABLE = 25,     /* several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE jobs as ONE launch:
+  HR_OP_EW_TABLE = 25,     /* several HR_OP_GRAD_TERM / HR_OP_BN_BWD_REDUCE / HR_OP_BN_BWD_FINALIZE / HR_OP_SUM_TERMS jobs as
+                              ONE launch (HR_OP_SUM_TERMS: i[4] = 1 if a job's BatchNorm is given as batch sums, and a
+                              job carries its eps bits in i[18] instead of i[16]):
                               p[0] = device array of HrOp jobs (slots as for the single op; i[16] = first block of the
                               job, i[17] = its blocks: hrnet_ew_table_blocks()), i[0] = jobs, i[1] = total blocks,
                               i[2] = kind of the jobs, i[3] = dtype */

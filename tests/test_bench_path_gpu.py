@@ -274,9 +274,20 @@ def _act_view(plan, kind, i, dtype):
     return (a.t if kind == 't' else a.g).view(dtype)
 
 
-def _written(op, C):
+def _table_jobs(op, plan, C):
+    """the HrOp jobs of a table-driven launch (HR_OP_EW_TABLE): the device table is one of the plan's kept tensors"""
+    import ctypes
+    t = next(t for t in plan.keep if t.dtype == torch.uint8 and t.data_ptr() == op.p[0])
+    raw = bytes(t.cpu().numpy().tobytes())
+    n = int(op.i[0])
+    return list((C.HrOp * n).from_buffer_copy(raw[:n * ctypes.sizeof(C.HrOp)]))
+
+
+def _written(op, C, plan=None):
     """(pointer, is_activation) slots an op writes that later ops of the same program read"""
     k = int(op.kind)
+    if k == C.OP_EW_TABLE and plan is not None:
+        return [w for job in _table_jobs(op, plan, C) for w in _written(job, C)]
     if k == C.OP_CONV:
         return [(op.p[5], True)] + ([(op.p[6], False)] if op.p[7] else [])       # + backward-statistics rows
     if k == C.OP_CONV_SUM:
@@ -371,7 +382,7 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
                     for t32, t16 in ((b32.scale, b16.scale), (b32.shift, b16.shift), (b32.mean, b16.mean), (b32.invstd, b16.invstd)):
                         t16.copy_(t32)
                 continue
-            for (q32, is_act), (q16, _) in zip(_written(o32, C), _written(o16, C)):
+            for (q32, is_act), (q16, _) in zip(_written(o32, C, p32), _written(o16, C, p16)):
                 if is_act:
                     if q32 not in a32:
                         continue                      # the NCHW outputs (compared below)

@@ -172,3 +172,21 @@ def test_batched_sum_backward_launches_change_nothing(monkeypatch):
     assert nb >= 16 and nu == 0 and plan_b.n_batched_jobs >= 150, (nb, nu, plan_b.n_batched_jobs)
     assert len(plan_b.bwd) < len(plan_u.bwd) - 150
     assert torch.equal(hm_b, hm_u) and torch.equal(g_b, g_u)
+
+
+def test_batched_forward_sums_change_nothing(monkeypatch):
+    """the sums of a HighResolutionModule's outputs as ONE table-driven launch (HR_OP_EW_TABLE of HR_OP_SUM_TERMS jobs)
+    run the same device code on the same operands as one launch per sum: bit-identical heat maps and gradients -
+    with per-BatchNorm finalize launches (deterministic) and with BatchNorm-from-sums in the prologue (default)"""
+    C = _C()
+    for det in ('1', '0'):
+        env = {'HRNET_DETERMINISTIC': '1'} if det == '1' else {'HRNET_DETERMINISTIC': '0'}
+        hm_b, g_b, plan_b, _ = _step(monkeypatch, dict(env, HRNET_BATCH_SUMFWD='1'))
+        hm_u, g_u, plan_u, _ = _step(monkeypatch, dict(env, HRNET_BATCH_SUMFWD='0'))
+        nb = sum(1 for o in plan_b.fwd.ops if int(o.kind) == C.OP_EW_TABLE)
+        nu = sum(1 for o in plan_u.fwd.ops if int(o.kind) == C.OP_EW_TABLE)
+        assert nb == 8 and nu == 0 and plan_b.n_batched_fwd_sums == 26, (nb, nu, plan_b.n_batched_fwd_sums)
+        if det == '1':
+            assert torch.equal(hm_b, hm_u) and torch.equal(g_b, g_u)
+        else:       # batch statistics by float atomics: two runs differ in summation order
+            assert float((hm_b - hm_u).norm() / hm_u.norm()) <= 2e-2
