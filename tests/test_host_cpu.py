@@ -130,11 +130,13 @@ def test_poseaggr_init_freezes_the_backbone_and_starts_as_the_identity_warp():
     from models import pose_hrnet_PoseAggr
     from utils.utils import get_optimizer
     cfg = get_cfg_defaults()
-    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'RHD', 'RHD_HRNet_w32_trainable_softmax_pose2dloss_v1.yaml'))
+    # the PoseAggr experiment file (the reference's key names: experiments/MHP/..._PoseAggr_v1.yaml)
+    cfg.merge_from_file(os.path.join(PKG, 'experiments', 'MHP', 'MHP_HRNet_w32_trainable_softmax_pose2dloss_PoseAggr_v1.yaml'))
+    assert cfg.MODEL.NAME == 'pose_hrnet_PoseAggr' and list(cfg.MODEL.DILATION_RATES) == [3, 6, 12, 18, 24]
+    assert cfg.MODEL.USE_WARPING_TRAIN and cfg.MODEL.USE_WARPING_TEST and cfg.MODEL.TRAINABLE_SOFTMAX
     cfg.MODEL.INIT_WEIGHTS = True
     cfg.MODEL.PRETRAINED = ''
-    cfg.MODEL.USE_WARPING_TRAIN = True
-    m = pose_hrnet_PoseAggr.get_pose_net(cfg, is_train=True)
+    m = eval('pose_hrnet_PoseAggr.get_pose_net')(cfg, is_train=True)       # (tools/train.py:113 dispatches by eval)
     named = dict(m.named_parameters())
     head = ('offset_feats.', 'offsets', 'deform_conv')
     for name, p in named.items():
