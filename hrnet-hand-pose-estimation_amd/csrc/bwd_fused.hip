@@ -658,7 +658,11 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   // every CU (165 us on 128 CUs)
   static const int big = getenv("HRNET_FUSED_CUS_BIG") ? atoi(getenv("HRNET_FUSED_CUS_BIG")) : 256;
   static const int cus128 = getenv("HRNET_FUSED_CUS_128") ? atoi(getenv("HRNET_FUSED_CUS_128")) : 128;   // (measurement)
-  int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb >= 2048 ? big : cus) * c.per_cu / ncb;
+  // (measurement: separate grids for the 32- and 64-channel instantiations, which run side by side on two lanes)
+  static const int cus32 = getenv("HRNET_FUSED_CUS32") ? atoi(getenv("HRNET_FUSED_CUS32")) : cus;
+  static const int cus64 = getenv("HRNET_FUSED_CUS64") ? atoi(getenv("HRNET_FUSED_CUS64")) : cus;
+  const int small = c.cop == 32 ? cus32 : cus64;
+  int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb >= 2048 ? big : small) * c.per_cu / ncb;
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   // even walks: every split takes the same number of tiles when possible

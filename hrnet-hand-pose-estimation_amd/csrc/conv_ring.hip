@@ -570,7 +570,14 @@ struct RingPlan {
 // large weight matrices) get FEW fat workgroups - 64 output channels x a whole image (or several 8x8 images), the
 // weight slices streamed once per workgroup - because what they move is mostly weights: 256 ch @ 8x8 as 512
 // workgroups of (one image, 32 channels) pulls 75 MB of weights through the CUs' load paths for a 6 MB layer.
+inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs);
 inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
+  // (measurement: HRNET_RING_IDS = bit mask of the instantiations that may be chosen)
+  static const int ids = getenv("HRNET_RING_IDS") ? atoi(getenv("HRNET_RING_IDS")) : 0x7e;
+  const RingPlan p = ring_plan_all(N, H, W, Cin, Cout, bs);
+  return ((ids >> p.id) & 1) ? p : RingPlan{0, 0, 0, 0, 0, 0};
+}
+inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs) {
   (void)N;
   static const int wide8 = getenv("HRNET_RING_TI8") ? atoi(getenv("HRNET_RING_TI8")) : 4;   // (measurement: 2 or 4)
   static const int wide16 = getenv("HRNET_RING_TI16") ? atoi(getenv("HRNET_RING_TI16")) : 1;   // (measurement: 1 or 2)
@@ -579,7 +586,8 @@ inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
   if (!bs && Cin == 64 && Cout >= 32 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 1, 32, 2};
   if (Cin >= 96 && Cout >= 64 && H == 8 && W == 8) return wide8 == 2 ? RingPlan{5, 8, 8, 2, 64, 0} : RingPlan{4, 8, 8, 4, 64, 0};
   if (Cin >= 96 && Cout >= 64 && H == 16 && W == 16 && wide16 == 2) return RingPlan{6, 16, 16, 2, 64, 0};
-  if (Cin >= 96 && Cout >= 64 && H >= 16 && W >= 16) return RingPlan{3, 16, 16, 1, 64, 0};
+  static const int id3_any = getenv("HRNET_RING_ID3_ANY") ? atoi(getenv("HRNET_RING_ID3_ANY")) : 0;   // (measurement)
+  if (Cin >= 96 && Cout >= 64 && H >= 16 && W >= 16 && (id3_any || (H <= 16 && W <= 16))) return RingPlan{3, 16, 16, 1, 64, 0};
   return RingPlan{0, 0, 0, 0, 0, 0};
 }
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
     }
   }
   // B fragments of the 4 pixel rows (K <= 128: up to 4 K steps stay in registers only for K = 32; reloaded otherwise)
-  const int nk = a.K / 32;
+  const int nk = (a.K + 31) / 32;     // (K = 48: the second K step is half empty - its upper lane groups feed zeros)
   bool pok[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) pok[g] = oy0 + g < a.H && xok;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
   const size_t xrow = (size_t)a.W * a.K * 2;          // bytes between pixel rows
   V16 bf0[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bf0[g] = pok[g] ? *(const V16*)(xp0 + g * xrow) : v16_zero();
+  for (int g = 0; g < 4; ++g) bf0[g] = (pok[g] && lg * 8 < a.K) ? *(const V16*)(xp0 + g * xrow) : v16_zero();
   __syncthreads();
 
   float* sl = (float*)(lds + a.sl_off);      // [4 waves][2][HM_CH]
@@ -211,10 +211,11 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
       V16 bf[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        bf[g] = k == 0 ? bf0[g] : (pok[g] ? *(const V16*)(xp0 + g * xrow + k * 64) : v16_zero());
+        bf[g] = k == 0 ? bf0[g] : ((pok[g] && k * 32 + lg * 8 < a.K) ? *(const V16*)(xp0 + g * xrow + k * 64) : v16_zero());
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        const V16 af = *(const V16*)(lds + (sb * 32 + f * 16 + li) * a.wrow + k * 64 + lg * 16);
+        const V16 af = (k * 32 + lg * 8 < a.K) ? *(const V16*)(lds + (sb * 32 + f * 16 + li) * a.wrow + k * 64 + lg * 16)
+                                               : v16_zero();
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[f][g] = mma16<T>(af, bf[g], acc[f][g]);
       }
@@ -512,13 +513,13 @@ extern "C" int hrnet_head_mix_rows(int N, int H, int W) {
 
 extern "C" int hrnet_head_mix_supported(int dtype, int C0, int Cout) {
   if (dtype == HR_F32) return C0 % 4 == 0 && C0 >= 4 && Cout % 4 == 0 && Cout >= 4 && Cout <= 512;
-  return dtype == HR_BF16 && C0 % 32 == 0 && C0 >= 32 && C0 <= 128 && Cout >= 8 && Cout % 8 == 0;
+  return dtype == HR_BF16 && C0 % 16 == 0 && C0 >= 16 && C0 <= 128 && Cout >= 8 && Cout % 8 == 0;
 }
 
 int hr_launch_head_mix(const HrOp& op, hipStream_t s) {
   const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], C0 = op.i[4], Cout = op.i[5], nup = op.i[6];
   HR_REQUIRE(hrnet_head_mix_supported(dtype, C0, Cout),
-             "head_mix: bf16 with C0 %% 32 == 0 (<= 128) or f32 with C0 %% 4 == 0 and Cout <= 512 (got dtype %d, %d, %d)",
+             "head_mix: bf16 with C0 %% 16 == 0 (<= 128) or f32 with C0 %% 4 == 0 and Cout <= 512 (got dtype %d, %d, %d)",
              dtype, C0, Cout);
   HR_REQUIRE(N > 0 && H > 0 && W > 0 && nup >= 0 && nup <= 3, "head_mix: shape");
   HR_REQUIRE(op.p[0] && op.p[1] && op.p[3], "head_mix: null pointer");

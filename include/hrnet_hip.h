@@ -437,7 +437,7 @@ int hrnet_bilinear_cat_bwd(int dtype, const void* dcat, void* const* dxs, const 
  * upsampling of t_1..t_nup (align_corners as hrnet_bilinear_cat), stores y once and gathers its batch statistics:
  *   rows_mode 0: stats = sums[8][2][Cout] (float atomics, as hrnet_conv2d with stats_atomic)
  *   rows_mode 1: stats = rows[hrnet_head_mix_rows(N,H,W)][2][Cout], one row per workgroup (deterministic)
- * bf16 (MFMA; C0 a multiple of 32) or f32 (plain FMAs: the validation path), Cout <= 512 (hrnet_head_mix_supported).
+ * bf16 (MFMA; C0 a multiple of 16, <= 128) or f32 (plain FMAs: the validation path), Cout <= 512 (hrnet_head_mix_supported).
  * w0: hrnet_pack_weights layout [Cout][C0].
  */
 int hrnet_head_mix(int dtype, const void* x0, const void* w0, const float* bias, void* y, float* stats, int rows_mode,

@@ -62,6 +62,7 @@ MIX_CASES = [
     (3, 8, 8, (64, 32), 96, False),                   # two branches, 192 pixels: a partial last block
     (1, 32, 32, (32,), 48, False),                    # no low-resolution term: a plain 1x1 conv + statistics
     (2, 32, 32, (32, 64, 128, 256), 480, True),       # align_corners=True (pose_hrnet_softmax.py:499-503)
+    (2, 48, 40, (48, 96, 192, 384), 720, False),      # the w48 head: K = 48 (a half-empty second K step), ragged tiles
 ]
 
 
@@ -94,7 +95,8 @@ def test_head_mix_equals_upsample_cat_conv(case, rows_mode, DT):
     nrows = C.call('hrnet_head_mix_rows', N, H, W)
     stats = torch.zeros((nrows if rows_mode else 8), 2, Cout, dtype=torch.float32, device=hh.DEV)
     bd = bias.to(hh.DEV)
-    assert C.call('hrnet_head_mix_supported', C.dtype_id(DT), cs[0], Cout) == 1
+    if C.call('hrnet_head_mix_supported', C.dtype_id(DT), cs[0], Cout) != 1:
+        pytest.skip('the fp32 form takes up to 512 output channels (the engine keeps the concat form there)')
     C.call('hrnet_head_mix', C.dtype_id(DT), xd[0].data_ptr(), w0.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), rows_mode,
            _pp(ts), _ip([H >> j for j in range(1, len(cs))]), _ip([W >> j for j in range(1, len(cs))]), len(ts),
            N, H, W, cs[0], Cout, 1 if align else 0, C.stream_ptr())
