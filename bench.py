@@ -510,7 +510,9 @@ def main():
         plan_ = model.hip().plan(x.shape[0], x.shape[2], x.shape[3], True, True)
         extra_out['launches_per_step'] = {'fwd': len(plan_.fwd), 'bwd': len(plan_.bwd),
                                           'fused_blocks': plan_.n_fused_blocks, 'deferred_wgrads': plan_.n_deferred_wgrads,
-                                          'fused_sums': plan_.n_fused_sums}
+                                          'fused_sums': plan_.n_fused_sums, 'head_mix': plan_.n_head_mix,
+                                          'batched_fwd_sums': plan_.n_batched_fwd_sums,
+                                          'batched_bwd_jobs': plan_.n_batched_jobs}
         extra_out['wgrad_slab_mb_per_step'] = round(plan_.slab_bytes / 1e6, 1)
         extra_out['critical_path_ms'] = kinds.pop('critical_path_ms')
         extra_out['op_kind_ms'] = {str(k): [v[0], round(v[1], 3)] for k, v in sorted(kinds.items())}
@@ -538,20 +540,19 @@ def main():
             extra_out['selfcheck'] = {'error': repr(e)[:200]}
         # (2) what the step costs in the form every rank of a data-parallel job runs (only the late region's weight
         # gradients deferred, none offloaded from lane 0: HRNET_DP_PLAN), on this one GPU: a SCALE record starts there
+        # Measured in a child process of its own (a second plan built in THIS process after the first one's buffers were
+        # freed ran 3 ms slower than the same plan in a fresh process: allocator state, not the plan).
         try:
-            os.environ['HRNET_DP_PLAN'] = '1'
-            model.hip().plans.clear()
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            extra_out['dp_mode_ms_per_step_1gpu'] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
-        finally:
-            os.environ.pop('HRNET_DP_PLAN', None)
-            model.hip().plans.clear()
+            import subprocess
+            env = dict(os.environ, HRNET_DP_PLAN='1')
+            cmd = [sys.executable, os.path.abspath(__file__), '--steps', '10', '--warmup', '5', '--batch', str(args.batch),
+                   '--dtype', args.dtype, '--arch', args.arch, '--no-cpu-baseline', '--no-roofline', '--no-selfcheck']
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+            extra_out['dp_mode_ms_per_step_1gpu'] = json.loads(line)['ms_per_step']
+        except Exception as e:        # noqa: BLE001
+            extra_out['dp_mode_ms_per_step_1gpu'] = None
+            extra_out['dp_mode_error'] = repr(e)[:200]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
