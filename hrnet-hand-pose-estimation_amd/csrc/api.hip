@@ -59,6 +59,7 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_EW_TABLE: e = hr_launch_ew_table(op, s); break;
     case HR_OP_HEAD_MIX: e = hr_launch_head_mix(op, s); break;
     case HR_OP_UPSAMPLE_T: e = hr_launch_upsample_t(op, s); break;
+    case HR_OP_HEAD_BWD: e = hr_launch_head_bwd(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");
@@ -353,6 +354,17 @@ extern "C" int hrnet_upsample_bilinear_t(int dtype, const void* g, void* const* 
     op.i[7 + 2 * k] = hs[k]; op.i[8 + 2 * k] = ws[k];
   }
   return hr_launch_upsample_t(op, (hipStream_t)stream);
+}
+
+extern "C" int hrnet_head_bwd(int dtype, int mode, const void* dy, const void* wT, const void* y, void* out,
+                              const float* bn_scale, const float* bn_shift, const float* coef, int inner_relu, int N,
+                              int H, int W, int K, int Cout, hr_stream_t stream) {
+  OP_BEGIN(HR_OP_HEAD_BWD);
+  const int iv[8] = {dtype, N, H, W, K, Cout, mode, inner_relu};
+  memcpy(op.i, iv, sizeof(iv));
+  op.p[0] = (void*)dy; op.p[1] = (void*)wT; op.p[2] = (void*)y; op.p[3] = out;
+  op.p[4] = (void*)bn_scale; op.p[5] = (void*)bn_shift; op.p[6] = (void*)coef;
+  return hr_launch_head_bwd(op, (hipStream_t)stream);
 }
 
 extern "C" int hrnet_im2col_stem(int dtype, const float* img_nchw, void* cols, int N, int C, int H, int W,

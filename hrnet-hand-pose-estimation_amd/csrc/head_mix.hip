@@ -39,6 +39,13 @@ struct HeadMixArgs {
   int tiles_x, tiles_y, chunks;
   int wrow;           // LDS bytes per weight row (K * 2 + 16)
   int sl_off;         // LDS byte offset of the per-wave statistics [4][2][HM_CH] floats
+  // backward of the layer BEHIND y (hrnet_head_bwd; MODE 1 / 2 of the kernels): x = dY of that layer [N][H][W][K],
+  // w = its transposed packed weight [Cout][K], so the product is d(ReLU output) of this layer - never stored
+  const char* yin;        // raw y [N][H][W][Cout]
+  const float* bn_scale;  // [Cout] BatchNorm affine of y (the ReLU mask is [scale*y + shift > 0]) or NULL: mask [y > 0]
+  const float* bn_shift;
+  const float* coef;      // MODE 2: [3][Cout] A, B, C of hrnet_bn_bwd_finalize
+  int inner_relu;
 };
 
 // bf16. 256 threads = 4 waves; wave v owns tile rows 4v .. 4v+3 (64 pixels = 4 MFMA pixel fragments; lane (li, lg)
@@ -48,6 +55,11 @@ struct HeadMixArgs {
 // same for all lanes: scalar registers) are interpolated along x once (2 taps), and each pixel row adds its two
 // y-weighted copies - 18 LDS reads and ~480 VALU operations per 32 outputs of a lane instead of 48 and ~1080.
 constexpr int HM_MAXR = 5;
+// MODE 0: the forward mix. MODE 1 / 2 (hrnet_head_bwd): the same K-step product is the gradient dz of the ReLU output
+// of y's BatchNorm (x = the gradient of the NEXT layer's output, w = that layer's transposed weight); it is masked
+// by the ReLU and either reduced to the BatchNorm-backward sums (1: rows of (sum dz, sum dz*y), one per pixel tile)
+// or turned into G = A*dz + B*y + C and stored (2) - dz itself (252 MB at batch 64) is never written or re-read.
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
   __syncthreads();
 
   float* sl = (float*)(lds + a.sl_off);      // [4 waves][2][HM_CH]
-  const bool stats = a.sums != nullptr || a.rows != nullptr;
+  const bool stats = MODE == 1 || (MODE == 0 && (a.sums != nullptr || a.rows != nullptr));
 #pragma unroll 1
   for (int sb = 0; sb < HM_CH / 32; ++sb) {
     const int n0 = c_base + sb * 32 + lg * 8;       // this lane's 8 output channels
@@ -268,14 +280,54 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
     float s1[8], s2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) s1[c] = s2[c] = 0.f;
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (pok[g] && n0 < a.Cout) {
-        *(V16*)(a.y + ((((size_t)img * a.H + oy0 + g) * a.W + ox) * a.Cout + n0) * 2) = v16_pack<T>(v[g]);
+      for (int g = 0; g < 4; ++g) {
+        if (pok[g] && n0 < a.Cout) {
+          *(V16*)(a.y + ((((size_t)img * a.H + oy0 + g) * a.W + ox) * a.Cout + n0) * 2) = v16_pack<T>(v[g]);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            s1[c] += v[g][c];
+            s2[c] = fmaf(v[g][c], v[g][c], s2[c]);
+          }
+        }
+      }
+    } else {
+      const bool cok = n0 < a.Cout;
+      V16 yv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        yv[g] = (pok[g] && cok) ? *(const V16*)(a.yin + ((((size_t)img * a.H + oy0 + g) * a.W + ox) * a.Cout + n0) * 2)
+                                : v16_zero();
+      float sc[8], sf[8], cA[8], cB[8], cC[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sc[c] = (a.bn_scale && cok) ? a.bn_scale[n0 + c] : 1.f;
+        sf[c] = (a.bn_shift && cok) ? a.bn_shift[n0 + c] : 0.f;
+        if constexpr (MODE == 2) {
+          cA[c] = cok ? a.coef[n0 + c] : 0.f;
+          cB[c] = cok ? a.coef[a.Cout + n0 + c] : 0.f;
+          cC[c] = cok ? a.coef[2 * a.Cout + n0 + c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float yf[8], o[8];
+        v16_unpack<T>(yv[g], yf);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          s1[c] += v[g][c];
-          s2[c] = fmaf(v[g][c], v[g][c], s2[c]);
+          const float z = fmaf(yf[c], sc[c], sf[c]);
+          const float dz = (!a.inner_relu || z > 0.f) ? v[g][c] : 0.f;
+          if constexpr (MODE == 1) {
+            s1[c] += dz;
+            s2[c] = fmaf(dz, yf[c], s2[c]);
+          } else {
+            o[c] = fmaf(cA[c], dz, fmaf(cB[c], yf[c], cC[c]));
+          }
+        }
+        if constexpr (MODE == 2) {
+          if (pok[g] && cok)
+            *(V16*)(a.y + ((((size_t)img * a.H + oy0 + g) * a.W + ox) * a.Cout + n0) * 2) = v16_pack<T>(o);
         }
       }
     }
@@ -311,6 +363,7 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
 // fp32 form (the validation path: plain FMAs, no MFMA, taps from global memory). One workgroup per pixel tile, as
 // above (so the rows of the deterministic statistics mean the same thing); thread (half, cv) owns the 4-channel
 // vector cv over the tile's even or odd rows, in pixel order - its sums are formed in a fixed order.
+template <int MODE>
 __global__ __launch_bounds__(256) void head_mix_f32_kernel(HeadMixArgs a) {
   __shared__ float sl[2][2][512];
   const int tid = threadIdx.x, half = tid >> 7, cv = tid & 127;
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(256) void head_mix_f32_kernel(HeadMixArgs a) {
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int img = b / a.tiles_y;
-  const bool stats = a.sums != nullptr || a.rows != nullptr;
+  const bool stats = MODE == 1 || (MODE == 0 && (a.sums != nullptr || a.rows != nullptr));
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (cv < ncv) {
     const float* w = (const float*)a.w;
@@ -359,11 +412,28 @@ __global__ __launch_bounds__(256) void head_mix_f32_kernel(HeadMixArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] += hy * (hx * f00[c] + lx * f01[c]) + ly * (hx * f10[c] + lx * f11[c]);
       }
-      *(f32x4*)((float*)a.y + p * a.Cout + n0) = f32x4{v[0], v[1], v[2], v[3]};
+      if constexpr (MODE == 0) {
+        *(f32x4*)((float*)a.y + p * a.Cout + n0) = f32x4{v[0], v[1], v[2], v[3]};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        s1[c] += v[c];
-        s2[c] = fmaf(v[c], v[c], s2[c]);
+        for (int c = 0; c < 4; ++c) {
+          s1[c] += v[c];
+          s2[c] = fmaf(v[c], v[c], s2[c]);
+        }
+      } else {
+        const f32x4 yv = *(const f32x4*)((const float*)a.yin + p * a.Cout + n0);
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float z = a.bn_scale ? fmaf(yv[c], a.bn_scale[n0 + c], a.bn_shift[n0 + c]) : yv[c];
+          const float dz = (!a.inner_relu || z > 0.f) ? v[c] : 0.f;
+          if constexpr (MODE == 1) {
+            s1[c] += dz;
+            s2[c] = fmaf(dz, yv[c], s2[c]);
+          } else {
+            o[c] = fmaf(a.coef[n0 + c], dz, fmaf(a.coef[a.Cout + n0 + c], yv[c], a.coef[2 * a.Cout + n0 + c]));
+          }
+        }
+        if constexpr (MODE == 2) *(f32x4*)((float*)a.y + p * a.Cout + n0) = f32x4{o[0], o[1], o[2], o[3]};
       }
     }
   }
@@ -516,6 +586,46 @@ extern "C" int hrnet_head_mix_supported(int dtype, int C0, int Cout) {
   return dtype == HR_BF16 && C0 % 16 == 0 && C0 >= 16 && C0 <= 128 && Cout >= 8 && Cout % 8 == 0;
 }
 
+static int head_launch(HeadMixArgs& a, int dtype, int mode, hipStream_t s) {
+  a.tiles_y = (a.H + HM_T - 1) / HM_T; a.tiles_x = (a.W + HM_T - 1) / HM_T;
+  a.chunks = (a.Cout + HM_CH - 1) / HM_CH;
+  a.wrow = a.K * 2 + 16;
+  int off = HM_CH * a.wrow;
+  for (int u = 0; u < a.nup; ++u) {
+    const int ch = mix_cap(a.uh[u], a.H), cw = mix_cap(a.uw[u], a.W);
+    a.cap[u] = ch > cw ? ch : cw;
+    a.toff[u] = off;
+    off += a.cap[u] * a.cap[u] * HM_TROW;
+  }
+  a.sl_off = off;
+  off += 4 * 2 * HM_CH * (int)sizeof(float);
+  const long long tiles = (long long)a.N * a.tiles_y * a.tiles_x;
+  if (dtype == HR_F32) {
+    HR_REQUIRE(tiles < (1ll << 31), "head_mix: grid");
+    if (mode == 0) hipLaunchKernelGGL(head_mix_f32_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(head_mix_f32_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(head_mix_f32_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return hr_check_launch("head_mix");
+  }
+  HR_REQUIRE(off <= 160 * 1024, "head_mix: %d bytes of LDS staging (scales too close to 1)", off);
+  HR_REQUIRE(tiles * a.chunks < (1ll << 31), "head_mix: grid");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)head_mix_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)head_mix_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)head_mix_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      hr_set_error("head_mix: hipFuncSetAttribute failed");
+      return HR_E_BADARG;
+    }
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(tiles * a.chunks));
+  if (mode == 0) hipLaunchKernelGGL(head_mix_tile_kernel<0>, grid, dim3(256), (size_t)off, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(head_mix_tile_kernel<1>, grid, dim3(256), (size_t)off, s, a);
+  else hipLaunchKernelGGL(head_mix_tile_kernel<2>, grid, dim3(256), (size_t)off, s, a);
+  return hr_check_launch("head_mix");
+}
+
 int hr_launch_head_mix(const HrOp& op, hipStream_t s) {
   const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], C0 = op.i[4], Cout = op.i[5], nup = op.i[6];
   HR_REQUIRE(hrnet_head_mix_supported(dtype, C0, Cout),
@@ -527,41 +637,35 @@ int hr_launch_head_mix(const HrOp& op, hipStream_t s) {
   a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.bias = (const float*)op.p[2]; a.y = (char*)op.p[3];
   if (op.i[14]) a.rows = (float*)op.p[4]; else a.sums = (float*)op.p[4];
   a.N = N; a.H = H; a.W = W; a.K = C0; a.Cout = Cout; a.nup = nup; a.align = op.i[7];
-  a.tiles_y = (H + HM_T - 1) / HM_T; a.tiles_x = (W + HM_T - 1) / HM_T;
-  a.chunks = (Cout + HM_CH - 1) / HM_CH;
-  a.wrow = C0 * 2 + 16;
-  int off = HM_CH * a.wrow;
   for (int u = 0; u < nup; ++u) {
     a.up[u] = (const char*)op.p[5 + u];
     a.uh[u] = op.i[8 + 2 * u]; a.uw[u] = op.i[9 + 2 * u];
     HR_REQUIRE(a.up[u] && a.uh[u] > 0 && a.uw[u] > 0 && a.uh[u] <= H && a.uw[u] <= W,
                "head_mix: low-resolution term %d (%dx%d)", u, a.uh[u], a.uw[u]);
-    const int ch = mix_cap(a.uh[u], H), cw = mix_cap(a.uw[u], W);
-    a.cap[u] = ch > cw ? ch : cw;
-    a.toff[u] = off;
-    off += a.cap[u] * a.cap[u] * HM_TROW;
   }
-  a.sl_off = off;
-  off += 4 * 2 * HM_CH * (int)sizeof(float);
-  const long long tiles = (long long)N * a.tiles_y * a.tiles_x;
-  if (dtype == HR_F32) {
-    HR_REQUIRE(tiles < (1ll << 31), "head_mix: grid");
-    hipLaunchKernelGGL(head_mix_f32_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
-    return hr_check_launch("head_mix");
-  }
-  HR_REQUIRE(off <= 160 * 1024, "head_mix: %d bytes of LDS staging (scales too close to 1)", off);
-  HR_REQUIRE(tiles * a.chunks < (1ll << 31), "head_mix: grid");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)head_mix_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      hr_set_error("head_mix: hipFuncSetAttribute failed");
-      return HR_E_BADARG;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(head_mix_tile_kernel, dim3((unsigned)(tiles * a.chunks)), dim3(256), (size_t)off, s, a);
-  return hr_check_launch("head_mix");
+  return head_launch(a, dtype, 0, s);
+}
+
+// Backward of the layer behind the head's BatchNorm (last_layer.3, pose_hrnet.py:341-346) fused with that BatchNorm's
+// backward: dz = W3^T dHM is a K = 32 product per pixel - cheaper to form twice than to store and re-read (252 MB each
+// way at batch 64). mode 1: rows[hrnet_head_mix_rows()][2][Cout] = (sum dz*mask, sum dz*mask*y) per pixel tile;
+// mode 2: out = A*(dz*mask) + B*y + C, the gradient of the raw y (coef from hrnet_bn_bwd_finalize on those rows).
+// slots: i = {dtype, N, H, W, K, Cout, mode, inner_relu}, p = {dY [N][H][W][K], wT packed [Cout][K] (hrnet_pack_weights
+//        mode 1 of the 1x1 layer), y raw [N][H][W][Cout], out (rows f32 | G), bn scale, bn shift, coef [3][Cout]}
+int hr_launch_head_bwd(const HrOp& op, hipStream_t s) {
+  const int dtype = op.i[0], N = op.i[1], H = op.i[2], W = op.i[3], K = op.i[4], Cout = op.i[5], mode = op.i[6];
+  HR_REQUIRE(hrnet_head_mix_supported(dtype, K, Cout), "head_bwd: dtype %d, K %d, Cout %d not served", dtype, K, Cout);
+  HR_REQUIRE(N > 0 && H > 0 && W > 0 && (mode == 1 || mode == 2), "head_bwd: shape / mode");
+  HR_REQUIRE(op.p[0] && op.p[1] && op.p[2] && op.p[3], "head_bwd: null pointer");
+  HR_REQUIRE((op.p[4] == nullptr) == (op.p[5] == nullptr), "head_bwd: scale/shift must come together");
+  HR_REQUIRE(mode == 1 || op.p[6], "head_bwd: mode 2 needs the coefficients");
+  HeadMixArgs a = {};
+  a.x = (const char*)op.p[0]; a.w = (const char*)op.p[1]; a.yin = (const char*)op.p[2];
+  if (mode == 1) a.rows = (float*)op.p[3]; else a.y = (char*)op.p[3];
+  a.bn_scale = (const float*)op.p[4]; a.bn_shift = (const float*)op.p[5]; a.coef = (const float*)op.p[6];
+  a.inner_relu = op.i[7];
+  a.N = N; a.H = H; a.W = W; a.K = K; a.Cout = Cout;
+  return head_launch(a, dtype, mode, s);
 }
 
 // 1 if the tile form serves these output sizes (align_corners=False, one integer scale of 2, 4 or 8 per output on both

@@ -28,6 +28,7 @@ OP_CONV_SUM = 24
 OP_EW_TABLE = 25
 OP_HEAD_MIX = 26
 OP_UPSAMPLE_T = 27
+OP_HEAD_BWD = 28
 LANE_SLOT = 18
 
 
@@ -120,6 +121,7 @@ _SIGS = {
     'hrnet_bilinear_cat': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 5 + [_c_vp],
     'hrnet_bilinear_cat_bwd': [_c_int, _c_vp, _pp, _ip, _ip, _ip] + [_c_int] * 6 + [_c_vp],
     'hrnet_head_mix': [_c_int] + [_c_vp] * 5 + [_c_int, _pp, _ip, _ip] + [_c_int] * 7 + [_c_vp],
+    'hrnet_head_bwd': [_c_int, _c_int] + [_c_vp] * 7 + [_c_int] * 6 + [_c_vp],
     'hrnet_head_mix_rows': [_c_int] * 3,
     'hrnet_head_mix_supported': [_c_int] * 3,
     'hrnet_upsample_bilinear_t': [_c_int, _c_vp, _pp, _ip, _ip] + [_c_int] * 7 + [_c_vp],

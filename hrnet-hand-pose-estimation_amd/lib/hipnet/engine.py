@@ -470,6 +470,7 @@ class Plan(object):
                 self._scratch(self.fwd, j, 0, 'stats')
         self._tape(('headmix', list(vals), crec, y, bnrec, ts, offs, align))
         self.n_head_mix = 1
+        self._head_y = y
         return Val(y, bnrec, True)
 
     # ---- network walk (reference: PoseHighResolutionNet.forward, pose_hrnet.py:511-568) ----
@@ -562,6 +563,8 @@ class Plan(object):
         align = bool(getattr(net.module, 'head_align_corners', False))
         c0 = cv['last_layer.0']
         self.n_head_mix = 0
+        self._head_y = None
+        self._head_bwd = None
         mix = (os.environ.get('HRNET_HEAD_MIX', '1') != '0' and not getattr(net.module, 'inter_from_cat', False)
                and 2 <= len(ys) <= 4 and all(v.bn is None and not v.relu for v in ys)
                and sum(v.act.C for v in ys) == c0.Cin and c0.Cin_pad == c0.Cin and c0.Cout_pad == c0.Cout
@@ -1070,7 +1073,22 @@ class Plan(object):
                     if crec.stem:
                         self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
                 self.bwd.lane = lane
-                if x.g is not None:
+                if (x is self._head_y and x.g is not None and xin.bn is not None and self.training and ks == 1
+                        and crec.mod.weight.shape[0] <= y.C and os.environ.get('HRNET_HEAD_BWD', '1') != '0'
+                        and C.call('hrnet_head_mix_supported', self.dtid, y.C, x.C) == 1):
+                    # the layer behind the head's BatchNorm (last_layer.3): its input gradient dz = W^T dY is a K = 32
+                    # product per pixel - formed here only to gather the BatchNorm-backward sums, and formed AGAIN by
+                    # the apply launch in _head_mix_backward (hrnet_head_bwd): dz is never stored or re-read
+                    nrows = C.call('hrnet_head_mix_rows', x.N, x.H, x.W)
+                    rows = self._f32(nrows * 2 * x.C)
+                    self.bwd.add(C.OP_HEAD_BWD, ints=(self.dtid, x.N, x.H, x.W, y.C, x.C, 1, 1 if xin.relu else 0),
+                                 ptrs=(C.ptr(y.g), C.ptr(crec.wd), C.ptr(x.t), C.ptr(rows), C.ptr(xin.bn.scale),
+                                       C.ptr(xin.bn.shift), None))
+                    x.bwd_rows = (rows, nrows)
+                    x.ginit = True
+                    self._head_bwd = (y, crec, 1 if xin.relu else 0)
+                    self.n_fused_bwdstats += 1
+                elif x.g is not None:
                     # input gradient = conv of dY with the transposed kernel (zero-stuffed for stride 2)
                     ptrs = [C.ptr(y.g), C.ptr(crec.wd), None, None, None, C.ptr(x.g), None, None, None, None, None]
                     last = (first_use.get(id(x)) == ti and use_lanes.get(id(x)) == {lane}
@@ -1131,7 +1149,19 @@ class Plan(object):
         self.bwd.tags[len(self.bwd)] = crec.prefix
         if not y.ginit:
             raise RuntimeError('no gradient reaches ' + y.name)
-        if bnrec is not None and not y.bn_done:
+        if bnrec is not None and not y.bn_done and self._head_bwd is not None:
+            # G = A*dz + B*y + C with dz = W3^T dHM formed again from the next layer's gradient (hrnet_head_bwd mode 2)
+            ny, ncrec, relu_flag = self._head_bwd
+            b, m = y.bn, y.bn.mod
+            rows, nrows = y.bwd_rows
+            self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(nrows, y.C, 1), floats=(y.pixels,),
+                         ptrs=(C.ptr(rows), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                               C.ptr(net.grad_of(m.weight)), C.ptr(net.grad_of(m.bias)), C.ptr(b.coef)))
+            self.bwd.add(C.OP_HEAD_BWD, ints=(self.dtid, y.N, y.H, y.W, ny.C, y.C, 2, relu_flag),
+                         ptrs=(C.ptr(ny.g), C.ptr(ncrec.wd), C.ptr(y.t), C.ptr(y.g), C.ptr(b.scale), C.ptr(b.shift),
+                               C.ptr(b.coef)))
+            y.bn_done = True
+        elif bnrec is not None and not y.bn_done:
             self._bn_backward(y, C.ptr(y.g), None, 0, relu_of.get(id(y), False))
         w = crec.mod.weight
         if crec.mod.bias is not None and not (bnrec is not None and self.training):

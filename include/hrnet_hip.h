@@ -77,6 +77,8 @@ enum {
                               i[2] = kind of the jobs, i[3] = dtype */
   HR_OP_HEAD_MIX = 26,     /* hrnet_head_mix: i = {dtype, N, H, W, C0, Cout, nup, align, h1, w1, h2, w2, h3, w3, rows
                               mode}, p = {x0, w0 packed, bias, y, statistics, t1, t2, t3} */
+  HR_OP_HEAD_BWD = 28,     /* hrnet_head_bwd: i = {dtype, N, H, W, K, Cout, mode, inner_relu}, p = {dY, wT, y, out, bn scale,
+                              bn shift, coef} */
   HR_OP_UPSAMPLE_T = 27    /* hrnet_upsample_bilinear_t: i = {dtype, N, H, W, C, nout, align, h1, w1, h2, w2, h3, w3,
                               streamed}, p = {G, out1, out2, out3} */
 };
@@ -445,6 +447,15 @@ int hrnet_head_mix(int dtype, const void* x0, const void* w0, const float* bias,
                    int align_corners, hr_stream_t stream);
 int hrnet_head_mix_rows(int N, int H, int W);
 int hrnet_head_mix_supported(int dtype, int C0, int Cout);
+/* Backward of the 1x1 layer BEHIND the head's BatchNorm + ReLU (last_layer[3] of pose_hrnet.py:341-346) fused with that
+ * BatchNorm's backward (autograd of nn.Conv2d / nn.ReLU / nn.BatchNorm2d): dz = wT dY (K = the layer's padded output
+ * channels) is formed per pixel tile and masked by [bn_scale*y + bn_shift > 0] (inner_relu), never stored.
+ *   mode 1: out = rows[hrnet_head_mix_rows(N,H,W)][2][Cout] f32, (sum dz, sum dz*y) per pixel tile (deterministic)
+ *   mode 2: out = G[N,H,W,Cout] = A*dz + B*y + C with coef = [3][Cout] from hrnet_bn_bwd_finalize on those rows
+ * wT: hrnet_pack_weights mode 1 of the layer's weight ([Cout][K]). Shapes as hrnet_head_mix_supported(dtype, K, Cout). */
+int hrnet_head_bwd(int dtype, int mode, const void* dy, const void* wT, const void* y, void* out, const float* bn_scale,
+                   const float* bn_shift, const float* coef, int inner_relu, int N, int H, int W, int K, int Cout,
+                   hr_stream_t stream);
 /* outs[k][N,hs[k],ws[k],C] = bilinear^T(G[N,H,W,C]) over ALL channels, k < nout <= 3: the gradients of t_j above
  * (autograd of F.upsample, pose_hrnet.py:561-563). Deterministic. Integer scales 2 / 4 / 8 with align_corners=0 take
  * ONE pass over G for all outputs (LDS-staged tiles); anything else (or streamed=1) a separable streamed walk per output. */

@@ -303,7 +303,9 @@ def _written(op, C, plan=None):
     if k == C.OP_HEAD_MIX:
         return [(op.p[3], True)]          # the head's raw output (its statistics feed a finalize launch)
     if k == C.OP_UPSAMPLE_T:
-        return [(op.p[1], True)]
+        return [(op.p[1 + j], True) for j in range(op.i[5])]
+    if k == C.OP_HEAD_BWD:
+        return [(op.p[3], op.i[6] == 2)]      # mode 1: statistics rows (a kept f32 tensor), mode 2: the gradient of raw y
     if k == C.OP_BN_FINALIZE:
         return [(op.p[6], False), (op.p[7], False), (op.p[8], False), (op.p[9], False)]
     if k == C.OP_BN_BWD_FINALIZE:

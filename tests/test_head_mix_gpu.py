@@ -215,3 +215,47 @@ def test_packed_column_slice_equals_dense_pack_of_the_slice():
     got = _pack_slice(w, 96, 224)
     ref, _, _ = hh.pack_weights(w[:, 96:224].contiguous(), DT, mode=0)
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize('DT', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 480), (1, 24, 40, 96), (3, 16, 16, 720)])
+def test_head_backward_fuses_last_layer_dgrad_with_the_batchnorm_backward(shape, DT):
+    """hrnet_head_bwd against autograd's pieces written out: dz = W3^T dHM (last_layer[3], pose_hrnet.py:341-346),
+    masked by the ReLU behind last_layer[1] (BatchNorm2d), then (mode 1) the BatchNorm-backward sums and (mode 2)
+    G = A*dz + B*y + C - what a dgrad conv, a reduction and an apply pass over a stored dz did before"""
+    hh, C = _h(), _C()
+    N, H, W, Cc = shape
+    if C.call('hrnet_head_mix_supported', C.dtype_id(DT), 32, Cc) != 1:
+        pytest.skip('the fp32 form takes up to 512 channels')
+    g = torch.Generator().manual_seed(29 + H + Cc)
+    nj = 21
+    dhm = torch.zeros(N, H, W, 32)
+    dhm[..., :nj] = torch.randn(N, H, W, nj, generator=g)
+    dhm = dhm.to(DT)
+    w3 = (torch.randn(nj, Cc, 1, 1, generator=g) / np.sqrt(Cc)).to(DT).float()
+    y = torch.randn(N, H, W, Cc, generator=g).to(DT)
+    scale = torch.rand(Cc, generator=g) + 0.5
+    shift = torch.randn(Cc, generator=g) * 0.3
+    coef = torch.randn(3, Cc, generator=g)
+    # reference
+    dz = dhm.float()[..., :nj] @ w3[:, :, 0, 0]                       # [N,H,W,Cc]
+    yf = y.float()
+    dzm = torch.where(yf * scale + shift > 0, dz, torch.zeros(()))
+    s1, s2 = dzm.sum((0, 1, 2)), (dzm * yf).sum((0, 1, 2))
+    G = coef[0] * dzm + coef[1] * yf + coef[2]
+    # device
+    wT, _, _ = hh.pack_weights(w3, DT, mode=1, cout_pad=32)            # [Cin = Cc][Cout_pad = 32]
+    dd, yd = dhm.to(hh.DEV), y.to(hh.DEV)
+    sc, sf, cf = scale.to(hh.DEV), shift.to(hh.DEV), coef.to(hh.DEV).contiguous()
+    rows = torch.full((C.call('hrnet_head_mix_rows', N, H, W), 2, Cc), float('nan'), device=hh.DEV)
+    C.call('hrnet_head_bwd', C.dtype_id(DT), 1, dd.data_ptr(), wT.data_ptr(), yd.data_ptr(), rows.data_ptr(),
+           sc.data_ptr(), sf.data_ptr(), None, 1, N, H, W, 32, Cc, C.stream_ptr())
+    out = torch.full((N, H, W, Cc), float('nan'), dtype=DT, device=hh.DEV)
+    C.call('hrnet_head_bwd', C.dtype_id(DT), 2, dd.data_ptr(), wT.data_ptr(), yd.data_ptr(), out.data_ptr(),
+           sc.data_ptr(), sf.data_ptr(), cf.data_ptr(), 1, N, H, W, 32, Cc, C.stream_ptr())
+    hh.sync()
+    r = rows.double().sum(0).cpu()
+    tol = 1e-4 * float(dzm.abs().sum((0, 1, 2)).max())                # f32 sums of exact products, another order
+    assert float((r[0] - s1.double()).abs().max()) <= tol and float((r[1] - (dzm * yf).double().sum((0, 1, 2))).abs().max()) <= 3 * tol
+    err = float((out.float().cpu() - G).abs().max())
+    assert err <= (2.0 ** -8 if DT == torch.bfloat16 else 1e-5) * float(G.abs().max()), (err, float(G.abs().max()))
