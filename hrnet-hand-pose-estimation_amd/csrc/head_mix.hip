@@ -379,19 +379,41 @@ __global__ __launch_bounds__(256) void head_mix_f32_kernel(HeadMixArgs a) {
     float b4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) b4[c] = a.bias ? a.bias[n0 + c] : 0.f;
+    // (K <= 32, the head's shapes: this thread's 4 weight rows stay in registers for the whole tile)
+    const bool wreg = a.K <= 32;
+    f32x4 wr[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        wr[c][k] = (wreg && k * 4 < a.K) ? *(const f32x4*)(w + (size_t)(n0 + c) * a.K + k * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = half; q < HM_T * HM_T; q += 2) {
       const int oy = ty * HM_T + q / HM_T, ox = tx * HM_T + q % HM_T;
       if (oy >= a.H || ox >= a.W) continue;
       const size_t p = ((size_t)img * a.H + oy) * a.W + ox;
       const float* x = (const float*)a.x + p * a.K;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < a.K; k += 4) {
-        const f32x4 xv = *(const f32x4*)(x + k);
+      if (wreg) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 wv = *(const f32x4*)(w + (size_t)(n0 + c) * a.K + k);
-          v[c] = fmaf(xv.x, wv.x, v[c]); v[c] = fmaf(xv.y, wv.y, v[c]);
-          v[c] = fmaf(xv.z, wv.z, v[c]); v[c] = fmaf(xv.w, wv.w, v[c]);
+        for (int k = 0; k < 8; ++k) {
+          if (k * 4 < a.K) {
+            const f32x4 xv = *(const f32x4*)(x + k * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = fmaf(xv.x, wr[c][k].x, v[c]); v[c] = fmaf(xv.y, wr[c][k].y, v[c]);
+              v[c] = fmaf(xv.z, wr[c][k].z, v[c]); v[c] = fmaf(xv.w, wr[c][k].w, v[c]);
+            }
+          }
+        }
+      } else {
+        for (int k = 0; k < a.K; k += 4) {
+          const f32x4 xv = *(const f32x4*)(x + k);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 wv = *(const f32x4*)(w + (size_t)(n0 + c) * a.K + k);
+            v[c] = fmaf(xv.x, wv.x, v[c]); v[c] = fmaf(xv.y, wv.y, v[c]);
+            v[c] = fmaf(xv.z, wv.z, v[c]); v[c] = fmaf(xv.w, wv.w, v[c]);
+          }
         }
       }
 #pragma unroll
