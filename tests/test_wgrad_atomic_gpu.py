@@ -192,3 +192,20 @@ def test_batched_forward_sums_change_nothing(monkeypatch):
             # batch statistics by float atomics: two runs differ in summation order, and a randomly initialised
             # 70-BatchNorm stack amplifies that (test_bench_path_gpu.py: whole-network band 0.3-0.45 for bf16)
             assert torch.isfinite(hm_b).all() and float((hm_b - hm_u).norm() / hm_u.norm()) <= 0.45
+
+
+def test_atomic_batch_statistics_differ_from_ordered_ones_by_f32_rounding_only(monkeypatch):
+    """the default training forward adds a conv's batch sums into 8 partial copies with float atomics
+    (hr_bn_from_sums: f64 combination, mean / E[x^2] - mean^2); HRNET_DETERMINISTIC=1 sums per-workgroup rows in a
+    fixed order. On identical inputs (the stem's first BatchNorm: its conv sees the same image and weights in both runs)
+    the two statistics agree to f32 summation noise - the gap between the two modes further down the network is the
+    amplification of that noise, not a different estimator"""
+    _, _, plan_a, m_a = _step(monkeypatch, {'HRNET_DETERMINISTIC': '0'})
+    mean_a, inv_a = plan_a.bns['bn1'].mean.clone(), plan_a.bns['bn1'].invstd.clone()
+    assert plan_a.bn_sums
+    _, _, plan_d, m_d = _step(monkeypatch, {'HRNET_DETERMINISTIC': '1'})
+    assert not plan_d.bn_sums
+    mean_d, inv_d = plan_d.bns['bn1'].mean, plan_d.bns['bn1'].invstd
+    sd = 1.0 / inv_d
+    assert float(((mean_a - mean_d).abs() / sd).max()) <= 2e-6          # in units of the channel's standard deviation
+    assert float(((inv_a - inv_d).abs() / inv_d).max()) <= 2e-6
