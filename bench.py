@@ -405,11 +405,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # (rehearsal of the N>1 code path on a one-GPU box: HRNET_BENCH_REHEARSE=1 puts every rank on cuda:0 and carries the
+    # exchange over gloo - it checks the path, its numbers mean nothing)
+    rehearse = os.environ.get('HRNET_BENCH_REHEARSE', '0') == '1'
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     if args.mode == 'dcn':
         return dcn_main(args, world, rank, dev)

@@ -129,6 +129,9 @@ class GradSync(object):
                 self._late = (hi, total)
         top = hi
         last = hi
+        # (with a late region the main region is a sixth of the gradient - 17 MB for w32: smaller buckets keep its
+        # exchange overlapped with the backward pass instead of leaving it to the end with the late region)
+        bucket_bytes = min(self.bucket_bytes, 4 << 20) if self._late is not None else self.bucket_bytes
         for op_index, prefix in marks:
             w = net.convs[prefix].mod.weight
             off = net.offsets[id(w)][0]
@@ -137,7 +140,7 @@ class GradSync(object):
                 hi = top
                 break
             last = off
-            if (hi - off) * 4 >= self.bucket_bytes:
+            if (hi - off) * 4 >= bucket_bytes:
                 self.cuts.append(op_index)
                 self._ranges[op_index] = (off, hi)
                 hi = off
