@@ -570,6 +570,7 @@ struct RingPlan {
 // large weight matrices) get FEW fat workgroups - 64 output channels x a whole image (or several 8x8 images), the
 // weight slices streamed once per workgroup - because what they move is mostly weights: 256 ch @ 8x8 as 512
 // workgroups of (one image, 32 channels) pulls 75 MB of weights through the CUs' load paths for a 6 MB layer.
+int g_ring_enabled = -1;
 inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs);
 inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
   // (measurement: HRNET_RING_IDS = bit mask of the instantiations that may be chosen)
@@ -586,12 +587,14 @@ inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs) {
   if (!bs && Cin == 64 && Cout >= 32 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 1, 32, 2};
   if (Cin >= 96 && Cout >= 64 && H == 8 && W == 8) return wide8 == 2 ? RingPlan{5, 8, 8, 2, 64, 0} : RingPlan{4, 8, 8, 4, 64, 0};
   if (Cin >= 96 && Cout >= 64 && H == 16 && W == 16 && wide16 == 2) return RingPlan{6, 16, 16, 2, 64, 0};
-  static const int id3_any = getenv("HRNET_RING_ID3_ANY") ? atoi(getenv("HRNET_RING_ID3_ANY")) : 0;   // (measurement)
+  // instantiation 3 serves any map of at least 16x16, but inside the training step it only wins on the 16x16 maps
+  // (w48: 96 channels at 32x32 lose 0.5 ms/step with it): hrnet_conv_ring_enable(2) (or HRNET_CONV_RING=2) lifts the
+  // restriction (tests of the overhanging-tile walk, measurements)
+  const bool id3_any = g_ring_enabled == 2;
   if (Cin >= 96 && Cout >= 64 && H >= 16 && W >= 16 && (id3_any || (H <= 16 && W <= 16))) return RingPlan{3, 16, 16, 1, 64, 0};
   return RingPlan{0, 0, 0, 0, 0, 0};
 }
 
-int g_ring_enabled = -1;
 #ifdef HR_RING_STAMP
 unsigned long long* g_ring_stamp = nullptr;
 #endif

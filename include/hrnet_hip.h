@@ -166,7 +166,9 @@ int hrnet_conv2d_bwdstats(int dtype, const void* x, const void* w, void* y, floa
  * pipeline (csrc/conv_ring.hip) behind hrnet_conv2d / hrnet_conv2d_bnref when the shape is served (bf16, Cin a
  * multiple of 32, no bias / accumulate / zero-stuffing, output statistics by atomics or none). This switch turns
  * that routing on (1, the default; environment HRNET_CONV_RING) or off (0: the tile-walking body of conv_body.h)
- * for A/B measurements and parity tests; returns the previous setting (-1: never decided).
+ * for A/B measurements and parity tests; 2: on, and the >= 96-channel 16x16-tile instantiation also takes maps larger
+ * than 16x16 (it serves them correctly but loses inside the training step, so 1 keeps it to 16x16 maps). Returns the
+ * previous setting (-1: never decided).
  */
 int hrnet_conv_ring_enable(int on);
 int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout);

@@ -66,6 +66,7 @@ FWD_CASES = [
 def test_ring_forward_matches_cpu_and_the_tile_walking_body(case):
     hh, C = _h(), _C()
     N, H, W, Cin, Cout, mode = case
+    C.call('hrnet_conv_ring_enable', 2)      # (2: the wide 16x16-tile instantiation on maps larger than 16x16 as well)
     assert C.call('hrnet_conv_ring_supported', 1, N, H, W, Cin, Cout) > 0
     g = torch.Generator().manual_seed(7 + N + Cin + Cout)
     x = _q(torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.3)
@@ -97,7 +98,7 @@ def test_ring_forward_matches_cpu_and_the_tile_walking_body(case):
     gb = torch.cat([gamma, beta]).to(hh.DEV).contiguous()
     sums_d, scale_d, shift_d = sums.to(hh.DEV), scale.to(hh.DEV), shift.to(hh.DEV)
     outs = []
-    for ring in (1, 0):
+    for ring in (2, 0):
         C.call('hrnet_conv_ring_enable', ring)
         y = torch.full((N, H, W, Cout), float('nan'), dtype=DT, device=hh.DEV)
         st = torch.zeros(8, 2, Cout, dtype=torch.float32, device=hh.DEV)
@@ -180,7 +181,7 @@ def test_ring_input_gradient_with_backward_statistics(case):
     dyd, byd = hh.nhwc(dy, DT), hh.nhwc(bs_y, DT)
     bmd = hh.nhwc(bs_m, DT) if bs_m is not None else None
     outs = []
-    for ring in (1, 0):
+    for ring in (2, 0):
         C.call('hrnet_conv_ring_enable', ring)
         if ring:
             assert C.call('hrnet_conv_ring_supported', 1, N, H, W, Cc, Cc) >= 3
