@@ -404,6 +404,10 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        # the four lanes of the recorded programs plus RCCL's stream: give every stream a hardware queue of its own
+        # (the HIP default is 4 per process; measured neutral at N=1, read before the runtime initialises)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     local = int(os.environ.get('LOCAL_RANK', '0'))
     # (rehearsal of the N>1 code path on a one-GPU box: HRNET_BENCH_REHEARSE=1 puts every rank on cuda:0 and carries the
     # exchange over gloo - it checks the path, its numbers mean nothing)
