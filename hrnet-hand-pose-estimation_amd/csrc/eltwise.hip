@@ -382,6 +382,13 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const GradArgs& a, int bid, 
       const int n = (int)(r / a.H);
       float dz[VEC], yv[VEC];
       compute_dz<T>(a, n, qy, qx, c, dz, yv, true);
+      // (optional) keep the pooled, masked gradient: the apply pass reads it instead of pooling and masking the
+      // full-resolution tensors a second time; the sums are those of the STORED values (rounded to T once)
+      if (a.dst) {
+        const V16 packed = v16_pack<T>(dz);
+        *(V16*)(a.dst + (size_t)(pix * cv + v) * 16) = packed;
+        v16_unpack<T>(packed, dz);
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         s1[j] += dz[j];
@@ -470,7 +477,7 @@ __device__ __forceinline__ GradArgs ew_grad_args(const HrOp& op, bool reduce) {
   a.accumulate2 = reduce ? 0 : op.i[8];
   a.dst2 = reduce ? nullptr : (char*)op.p[7];
   a.partials = reduce ? (float*)op.p[0] : nullptr;
-  a.dst = reduce ? nullptr : (char*)op.p[0];
+  a.dst = reduce ? (char*)op.p[6] : (char*)op.p[0];      // (reduce: optional store of the pooled, masked gradient)
   a.coef = reduce ? nullptr : (const float*)op.p[6];
   a.g = (const char*)op.p[1]; a.mask = (const char*)op.p[2]; a.y = (const char*)op.p[3];
   a.scale = (const float*)op.p[4]; a.shift = (const float*)op.p[5];
@@ -1154,7 +1161,7 @@ static int fill_grad_args(const HrOp& op, GradArgs& a, bool reduce) {
   a.accumulate2 = reduce ? 0 : op.i[8];
   a.dst2 = reduce ? nullptr : (char*)op.p[7];
   if (reduce) {
-    a.partials = (float*)op.p[0]; a.dst = nullptr; a.coef = nullptr;
+    a.partials = (float*)op.p[0]; a.dst = (char*)op.p[6]; a.coef = nullptr;
   } else {
     a.dst = (char*)op.p[0]; a.partials = nullptr; a.coef = (const float*)op.p[6];
     HR_REQUIRE(!a.dst2 || (a.sh == 0 && !a.inner_relu), "grad_term: dst2 needs sh=0 and no inner ReLU");

@@ -715,6 +715,12 @@ class Plan(object):
         blocks = C.call('hrnet_reduce_blocks', y.N, y.H, y.W, y.C)
         self.max_bwd_part = max(self.max_bwd_part, blocks * 2 * y.C)
         m = b.mod
+        # a reduction pass (no sums gathered by a producer) pools and masks the upstream gradient: it keeps that dz in
+        # y.g, and the apply pass reads it from there instead of pooling and masking the full-resolution tensors
+        # again (an up-sampled fuse term of branch 0 re-read 2 x 16.8 MB per term). HRNET_KEEP_DZ=0: both passes pool.
+        keep_dz = None
+        if y.bwd_rows is None and g_src != C.ptr(y.g) and os.environ.get('HRNET_KEEP_DZ', '1') != '0':
+            keep_dz = C.ptr(y.g)
         if y.bwd_rows is not None:
             # the dgrad conv that finished g_src already gathered (sum dz, sum dz*y) in its epilogue
             rows, blocks = y.bwd_rows
@@ -725,13 +731,13 @@ class Plan(object):
         elif self._batch is not None:
             part = self._f32(blocks * 2 * y.C)          # (a job of a batched launch: partial rows of its own)
             self._emit(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
-                       ptrs=(C.ptr(part), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
+                       ptrs=(C.ptr(part), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), keep_dz))
             self._emit(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
                        ptrs=(C.ptr(part), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
                              C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
         else:
             i = self.bwd.add(C.OP_BN_BWD_REDUCE, ints=(self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0),
-                             ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift)))
+                             ptrs=(None, g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), keep_dz))
             self._scratch(self.bwd, i, 0, 'bwdpart')
             j = self.bwd.add(C.OP_BN_BWD_FINALIZE, ints=(blocks, y.C, 1), floats=(y.pixels,),
                              ptrs=(None, C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
@@ -739,6 +745,9 @@ class Plan(object):
             self._scratch(self.bwd, j, 0, 'bwdpart')
         ints = [self.dtid, y.N, y.H, y.W, y.C, sh, 1 if inner_relu else 0, 0, 0]
         ptrs = [C.ptr(y.g), g_src, mask, C.ptr(y.t), C.ptr(b.scale), C.ptr(b.shift), C.ptr(b.coef), None]
+        if keep_dz is not None:
+            ints[5], ints[6] = 0, 0                   # dz as the reduction stored it: pooled and masked already
+            ptrs[1], ptrs[2] = keep_dz, None
         if extra is not None:
             assert sh == 0 and not inner_relu
             ints[8] = 1 if extra.ginit else 0

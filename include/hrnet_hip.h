@@ -51,7 +51,9 @@ enum {
   HR_OP_BN_FINALIZE = 4,   /* stat partials -> scale/shift (+ running stats) */
   HR_OP_SUM_TERMS = 5,     /* out = relu(sum_t relu_t(affine_t(up_t(src_t)))) */
   HR_OP_GRAD_TERM = 6,     /* dst (+)= A*pool(g*mask) + B*y + C */
-  HR_OP_BN_BWD_REDUCE = 7, /* per-channel sum(dz), sum(dz*y) partials */
+  HR_OP_BN_BWD_REDUCE = 7, /* per-channel sum(dz), sum(dz*y) partials; p[6] (optional): dz itself (pooled, masked,
+                              [N,H,W,C] in the compute dtype) stored for the apply pass, which then runs
+                              HR_OP_GRAD_TERM with g = that tensor, sh = 0 and no masks (in place) */
   HR_OP_BN_BWD_FINALIZE = 8,
   HR_OP_BILINEAR_CAT = 9,
   HR_OP_BILINEAR_CAT_BWD = 10,
