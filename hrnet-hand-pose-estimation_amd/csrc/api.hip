@@ -60,6 +60,7 @@ static int run_one(const HrOp& op, hipStream_t s, int k) {
     case HR_OP_HEAD_MIX: e = hr_launch_head_mix(op, s); break;
     case HR_OP_UPSAMPLE_T: e = hr_launch_upsample_t(op, s); break;
     case HR_OP_HEAD_BWD: e = hr_launch_head_bwd(op, s); break;
+    case HR_OP_POOL_REDUCE: e = hr_launch_pool_reduce(op, s); break;
     case HR_OP_EVENT_RECORD:
       e = hipEventRecord((hipEvent_t)op.p[0], s) == hipSuccess ? HR_OK : HR_E_LAUNCH;
       if (e) hr_set_error("event record failed");

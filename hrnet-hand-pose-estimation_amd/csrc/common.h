@@ -237,3 +237,4 @@ int hr_launch_ew_table(const HrOp& op, hipStream_t s);
 int hr_launch_head_mix(const HrOp& op, hipStream_t s);
 int hr_launch_upsample_t(const HrOp& op, hipStream_t s);
 int hr_launch_head_bwd(const HrOp& op, hipStream_t s);
+int hr_launch_pool_reduce(const HrOp& op, hipStream_t s);

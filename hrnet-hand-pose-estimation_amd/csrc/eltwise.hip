@@ -412,6 +412,187 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const GradArgs& a, int bid, 
   }
 }
 
+// The reduction pass of SEVERAL up-sampled terms of one fuse sum at once (HR_OP_POOL_REDUCE): output i of a
+// HighResolutionModule adds nearest-up-sampled terms from the branches below it (pose_hrnet.py:257-264), so the
+// BatchNorm backward of the term from branch i + l needs G_i (masked by the sum's ReLU) pooled over 2^l x 2^l blocks -
+// the blocks nest, so ONE walk over G_i and the mask forms every level (level l + 1 = the sum of four level-l values,
+// in f32), stores each level's dz (rounded to T once; the apply pass reads it) and its (sum dz, sum dz*y) partials.
+// Before, every term pooled the full-resolution tensors on its own (three terms on branch 0: 3 x 33.6 MB).
+struct PoolArgs {
+  const char* g;         // [N][H][W][C] upstream gradient of the sum output
+  const char* mask;      // [N][H][W][C] the sum output (ReLU mask [> 0]) or NULL
+  const char* y[3];      // raw conv output of the term at level l + 1: [N][H >> (l+1)][W >> (l+1)][C]
+  char* dz[3];           // same shape: pooled, masked gradient (out)
+  float* partials[3];    // [blocks][2][C]
+  int N, H, W, C, nlev;
+};
+
+// One thread per level-1 block (2x2 pixels) and channel vector; the 256/cv "rows" of a workgroup are consecutive
+// level-1 blocks in nested (Morton) order, so the four children of a level-2 block are rows 4k .. 4k+3 and the sixteen
+// grand-children of a level-3 block rows 16k .. 16k+15: the higher levels are added through LDS in a fixed order.
+template <typename T, int NLEV>
+__device__ __forceinline__ void pool_reduce_block(const PoolArgs& a, int bid, int nb, float* red) {
+  constexpr int VEC = TT<T>::VEC;
+  const int cv = a.C / VEC;
+  constexpr int GROUP = NLEV == 3 ? 16 : (NLEV == 2 ? 4 : 1);      // level-1 blocks per coarsest block
+  const int rows = 256 / cv / GROUP * GROUP;    // level-1 blocks per workgroup step: whole coarsest blocks
+  const int v = threadIdx.x % cv, row = threadIdx.x / cv;
+  const int c = v * VEC;
+  float s1[3][VEC], s2[3][VEC];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[l][j] = s2[l][j] = 0.f;
+  const int Ht = a.H >> NLEV, Wt = a.W >> NLEV;
+  const long long ntop = (long long)a.N * Ht * Wt;
+  const long long n1 = ntop * GROUP;                                // level-1 blocks, nested order
+  float* l1 = red;                      // [rows][cv][VEC] level-1 (then level-2) values of the step
+  for (long long base = (long long)bid * rows; base < n1; base += (long long)nb * rows) {
+    const long long q = base + row;
+    const bool live = row < rows && q < n1;
+    float d1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) d1[j] = 0.f;
+    int n = 0, y1 = 0, x1 = 0;
+    if (live) {
+      const long long top = q / GROUP;
+      const int sub = (int)(q % GROUP);
+      const int tx = (int)(top % Wt);
+      const long long r = top / Wt;
+      const int ty = (int)(r % Ht);
+      n = (int)(r / Ht);
+      // nested order: sub = (child of level 3) * 4 + (child of level 2); a child index is (dy << 1) | dx
+      const int c3 = NLEV == 3 ? sub >> 2 : 0, c2 = NLEV >= 2 ? sub & 3 : 0;
+      int by = ty, bx = tx;
+      if (NLEV == 3) { by = by * 2 + (c3 >> 1); bx = bx * 2 + (c3 & 1); }
+      if (NLEV >= 2) { by = by * 2 + (c2 >> 1); bx = bx * 2 + (c2 & 1); }
+      y1 = by; x1 = bx;                          // level-1 coordinates
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const size_t off = ((size_t)((n * a.H + y1 * 2 + (p >> 1)) * a.W + x1 * 2 + (p & 1)) * a.C + c) * sizeof(T);
+        float gv[VEC];
+        v16_unpack<T>(*(const V16*)(a.g + off), gv);
+        if (a.mask) {
+          float mv[VEC];
+          v16_unpack<T>(*(const V16*)(a.mask + off), mv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) gv[j] = mv[j] > 0.f ? gv[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d1[j] += gv[j];
+      }
+      const size_t o1 = ((size_t)((n * (a.H >> 1) + y1) * (a.W >> 1) + x1) * a.C + c) * sizeof(T);
+      const V16 packed = v16_pack<T>(d1);
+      *(V16*)(a.dz[0] + o1) = packed;
+      float dr[VEC], yv[VEC];
+      v16_unpack<T>(packed, dr);
+      v16_unpack<T>(*(const V16*)(a.y[0] + o1), yv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[0][j] += dr[j];
+        s2[0][j] = fmaf(dr[j], yv[j], s2[0][j]);
+      }
+    }
+    if constexpr (NLEV >= 2) {
+      __syncthreads();                           // (the previous step's values have been read)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) l1[(row * cv + v) * VEC + j] = d1[j];
+      __syncthreads();
+      float d2[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d2[j] = 0.f;
+      const bool head2 = live && (row & 3) == 0;
+      if (head2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) d2[j] += l1[((row + k) * cv + v) * VEC + j];
+        const int y2 = y1 >> 1, x2 = x1 >> 1;
+        const size_t o2 = ((size_t)((n * (a.H >> 2) + y2) * (a.W >> 2) + x2) * a.C + c) * sizeof(T);
+        const V16 packed = v16_pack<T>(d2);
+        *(V16*)(a.dz[1] + o2) = packed;
+        float dr[VEC], yv[VEC];
+        v16_unpack<T>(packed, dr);
+        v16_unpack<T>(*(const V16*)(a.y[1] + o2), yv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          s1[1][j] += dr[j];
+          s2[1][j] = fmaf(dr[j], yv[j], s2[1][j]);
+        }
+      }
+      if constexpr (NLEV == 3) {
+        __syncthreads();
+        if ((row & 3) == 0) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) l1[(row * cv + v) * VEC + j] = d2[j];
+        }
+        __syncthreads();
+        if (live && (row & 15) == 0) {
+          float d3[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) d3[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) d3[j] += l1[((row + 4 * k) * cv + v) * VEC + j];
+          const int y3 = y1 >> 2, x3 = x1 >> 2;
+          const size_t o3 = ((size_t)((n * (a.H >> 3) + y3) * (a.W >> 3) + x3) * a.C + c) * sizeof(T);
+          const V16 packed = v16_pack<T>(d3);
+          *(V16*)(a.dz[2] + o3) = packed;
+          float dr[VEC], yv[VEC];
+          v16_unpack<T>(packed, dr);
+          v16_unpack<T>(*(const V16*)(a.y[2] + o3), yv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            s1[2][j] += dr[j];
+            s2[2][j] = fmaf(dr[j], yv[j], s2[2][j]);
+          }
+        }
+      }
+    }
+  }
+  // per level: the workgroup's partial row, rows added in a fixed order (as bn_bwd_reduce_block)
+#pragma unroll
+  for (int l = 0; l < NLEV; ++l) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[(threadIdx.x * 2 + 0) * VEC + j] = s1[l][j];
+      red[(threadIdx.x * 2 + 1) * VEC + j] = s2[l][j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * a.C; o += 256) {
+      const int which = o / a.C, ch = o % a.C;
+      const int vv = ch / VEC, jj = ch % VEC;
+      float sacc = 0.f;
+      for (int r = 0; r < rows; ++r) sacc += red[((r * cv + vv) * 2 + which) * VEC + jj];
+      a.partials[l][((size_t)bid * 2 + which) * a.C + ch] = sacc;
+    }
+  }
+}
+
+__host__ __device__ inline void pool_args_from_op(const HrOp& op, PoolArgs& a) {
+  // slots: i = {dtype, N, H, W, C, nlev}, p = {g, mask, y1, dz1, partials1, y2, dz2, partials2, y3, dz3, partials3}
+  a.N = op.i[1]; a.H = op.i[2]; a.W = op.i[3]; a.C = op.i[4]; a.nlev = op.i[5];
+  a.g = (const char*)op.p[0]; a.mask = (const char*)op.p[1];
+  for (int l = 0; l < 3; ++l) {
+    a.y[l] = (const char*)op.p[2 + 3 * l]; a.dz[l] = (char*)op.p[3 + 3 * l]; a.partials[l] = (float*)op.p[4 + 3 * l];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void pool_reduce_dispatch(const PoolArgs& a, int bid, int nb, float* red) {
+  if (a.nlev == 1) pool_reduce_block<T, 1>(a, bid, nb, red);
+  else if (a.nlev == 2) pool_reduce_block<T, 2>(a, bid, nb, red);
+  else pool_reduce_block<T, 3>(a, bid, nb, red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_reduce_kernel(PoolArgs a) {
+  __shared__ float red[256 * 2 * TT<T>::VEC];
+  pool_reduce_dispatch<T>(a, (int)blockIdx.x, (int)gridDim.x, red);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(GradArgs a) {
   __shared__ float red[256 * 2 * TT<T>::VEC];
@@ -490,6 +671,16 @@ __global__ __launch_bounds__(256) void grad_term_table_kernel(const HrOp* tab, i
   const HrOp& op = ew_table_find(tab, n, local);
   const GradArgs a = ew_grad_args(op, false);
   grad_term_block<T>(a, local, op.i[17]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_reduce_table_kernel(const HrOp* tab, int n) {
+  __shared__ float red[256 * 2 * TT<T>::VEC];
+  int local;
+  const HrOp& op = ew_table_find(tab, n, local);
+  PoolArgs a;
+  pool_args_from_op(op, a);
+  pool_reduce_dispatch<T>(a, local, op.i[17], red);
 }
 
 // the forward sums of a HighResolutionModule's outputs (one per branch) as ONE launch: no fork / join around them
@@ -1240,6 +1431,7 @@ extern "C" int hrnet_ew_table_blocks(int kind, int dtype, int N, int H, int W, i
   if (kind == HR_OP_BN_BWD_REDUCE) return hrnet_reduce_blocks(N, H, W, C);
   if (kind == HR_OP_BN_BWD_FINALIZE) return (C + 31) / 32;
   if (kind == HR_OP_SUM_TERMS) return (int)ew_grid((long long)N * H * W * (C / vec));      // (output size)
+  if (kind == HR_OP_POOL_REDUCE) return hrnet_reduce_blocks(N, H, W, C);      // (N, H, W: the FIRST level's size, H/2 x W/2)
   return 0;
 }
 
@@ -1256,6 +1448,9 @@ int hr_launch_ew_table(const HrOp& op, hipStream_t s) {
     else hipLaunchKernelGGL(bn_bwd_reduce_table_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
   } else if (kind == HR_OP_BN_BWD_FINALIZE) {
     hipLaunchKernelGGL(bn_bwd_finalize_table_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, tab, n);
+  } else if (kind == HR_OP_POOL_REDUCE) {
+    if (dtype == HR_F32) hipLaunchKernelGGL(pool_reduce_table_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
+    else hipLaunchKernelGGL(pool_reduce_table_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, tab, n);
   } else if (kind == HR_OP_SUM_TERMS) {
     // op.i[4] != 0: some job's BatchNorm comes as batch sums (the instantiation with the coefficient table)
     const bool sums = op.i[4] != 0;
@@ -1270,6 +1465,22 @@ int hr_launch_ew_table(const HrOp& op, hipStream_t s) {
     HR_REQUIRE(false, "ew_table: kind %d cannot be batched", kind);
   }
   return hr_check_launch("ew_table");
+}
+
+// HR_OP_POOL_REDUCE as a launch of its own (slots: pool_args_from_op)
+int hr_launch_pool_reduce(const HrOp& op, hipStream_t s) {
+  PoolArgs a;
+  pool_args_from_op(op, a);
+  const int dtype = op.i[0], vec = dtype == HR_F32 ? 4 : 8;
+  HR_REQUIRE(dtype == HR_F32 || dtype == HR_BF16, "pool_reduce: dtype");
+  HR_REQUIRE(a.g && a.nlev >= 1 && a.nlev <= 3 && a.N > 0 && a.C > 0 && a.C % vec == 0 && a.C / vec <= 256, "pool_reduce: args");
+  HR_REQUIRE(a.H % (1 << a.nlev) == 0 && a.W % (1 << a.nlev) == 0, "pool_reduce: %dx%d is not a multiple of 2^%d", a.H, a.W, a.nlev);
+  for (int l = 0; l < a.nlev; ++l) HR_REQUIRE(a.y[l] && a.dz[l] && a.partials[l], "pool_reduce: level %d pointers", l + 1);
+  HR_REQUIRE(256 / (a.C / vec) >= (a.nlev == 3 ? 16 : a.nlev == 2 ? 4 : 1), "pool_reduce: %d channels are too many for %d levels", a.C, a.nlev);
+  const int blocks = hrnet_reduce_blocks(a.N, a.H >> 1, a.W >> 1, a.C);
+  if (dtype == HR_F32) hipLaunchKernelGGL(pool_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(pool_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hr_check_launch("pool_reduce");
 }
 
 int hr_launch_bn_bwd_finalize(const HrOp& op, hipStream_t s) {

@@ -29,6 +29,7 @@ OP_EW_TABLE = 25
 OP_HEAD_MIX = 26
 OP_UPSAMPLE_T = 27
 OP_HEAD_BWD = 28
+OP_POOL_REDUCE = 29
 LANE_SLOT = 18
 
 

@@ -707,7 +707,7 @@ class Plan(object):
         return outs
 
     # ---- backward recording ---------------------------------------------------------------
-    def _bn_backward(self, y, g_src, mask, sh, inner_relu, extra=None):
+    def _bn_backward(self, y, g_src, mask, sh, inner_relu, extra=None, pooled=None):
         """BatchNorm backward for raw act y: reads the upstream gradient from g_src (pooled over
         2^sh blocks, masked by mask>0 and the BN's own ReLU), writes d(raw) into y.g. `extra`: an
         identity term of the same sum whose gradient (the same dz) is written by the same pass."""
@@ -721,7 +721,16 @@ class Plan(object):
         keep_dz = None
         if y.bwd_rows is None and g_src != C.ptr(y.g) and os.environ.get('HRNET_KEEP_DZ', '1') != '0':
             keep_dz = C.ptr(y.g)
-        if y.bwd_rows is not None:
+        if pooled is not None:
+            # the reduction ran as one level of a HR_OP_POOL_REDUCE job (its dz is in y.g, its partial rows in `pooled`)
+            part, pblocks = pooled
+            keep_dz = C.ptr(y.g)
+            self._emit(C.OP_BN_BWD_FINALIZE, ints=(pblocks, y.C, 1), floats=(y.pixels,),
+                       ptrs=(C.ptr(part), C.ptr(m.weight), C.ptr(b.mean), C.ptr(b.invstd),
+                             C.ptr(self.net.grad_of(m.weight)), C.ptr(self.net.grad_of(m.bias)), C.ptr(b.coef)))
+        if pooled is not None:
+            pass
+        elif y.bwd_rows is not None:
             # the dgrad conv that finished g_src already gathered (sum dz, sum dz*y) in its epilogue
             rows, blocks = y.bwd_rows
             assert sh == 0
@@ -780,7 +789,7 @@ class Plan(object):
         if batch is None:
             return
         self.bwd.lane = 0
-        for kind in (C.OP_BN_BWD_REDUCE, C.OP_BN_BWD_FINALIZE, C.OP_GRAD_TERM):
+        for kind in (C.OP_POOL_REDUCE, C.OP_BN_BWD_REDUCE, C.OP_BN_BWD_FINALIZE, C.OP_GRAD_TERM):
             jobs = batch[kind]
             if not jobs:
                 continue
@@ -788,6 +797,8 @@ class Plan(object):
             for op in jobs:
                 if kind == C.OP_BN_BWD_FINALIZE:
                     nb = C.call('hrnet_ew_table_blocks', kind, self.dtid, 1, 1, 1, op.i[1])
+                elif kind == C.OP_POOL_REDUCE:
+                    nb = C.call('hrnet_ew_table_blocks', kind, self.dtid, op.i[1], op.i[2] >> 1, op.i[3] >> 1, op.i[4])
                 else:
                     nb = C.call('hrnet_ew_table_blocks', kind, self.dtid, op.i[1], op.i[2], op.i[3], op.i[4])
                 op.i[16], op.i[17] = block, nb
@@ -917,7 +928,7 @@ class Plan(object):
                     # a few MB, three or four per lane in a row) runs as three batched launches on lane 0 instead:
                     # no fork / join around it
                     if e[0] == 'join':
-                        self._batch = {C.OP_BN_BWD_REDUCE: [], C.OP_BN_BWD_FINALIZE: [], C.OP_GRAD_TERM: []}
+                        self._batch = {C.OP_POOL_REDUCE: [], C.OP_BN_BWD_REDUCE: [], C.OP_BN_BWD_FINALIZE: [], C.OP_GRAD_TERM: []}
                     else:
                         self._flush_batch()
                 elif e[0] == 'join':
@@ -967,6 +978,24 @@ class Plan(object):
                 plain = [t for t, sh in zip(terms, shifts) if not (t.act.bn is not None and t.act.nuse == 1)]
                 # one BN term and one identity/accumulating term share dz: written by the same pass
                 paired = (fusable[0], plain[0]) if fusable and plain else (None, None)
+                # the nearest-up-sampled terms (from the branches below this output): ONE walk over out.g and the mask
+                # pools every level, stores each level's dz and gathers its sums (HR_OP_POOL_REDUCE)
+                pooled = {}
+                ups = sorted([(sh, t) for t, sh in zip(terms, shifts)
+                              if sh > 0 and t.act.bn is not None and t.act.nuse == 1 and self.training and not t.relu
+                              and t.act.bwd_rows is None], key=lambda q: q[0])
+                if (ups and [q[0] for q in ups] == list(range(1, len(ups) + 1)) and len(ups) <= 3
+                        and out.H % (1 << len(ups)) == 0 and out.W % (1 << len(ups)) == 0
+                        and 256 // (out.C // (4 if self.dt == torch.float32 else 8)) >= 4 ** (len(ups) - 1)
+                        and os.environ.get('HRNET_POOL_REDUCE', '1') != '0' and os.environ.get('HRNET_KEEP_DZ', '1') != '0'):
+                    L = len(ups)
+                    pblocks = C.call('hrnet_ew_table_blocks', C.OP_POOL_REDUCE, self.dtid, out.N, out.H >> 1, out.W >> 1, out.C)
+                    ptrs = [C.ptr(out.g), mask]
+                    for sh, t in ups:
+                        part = self._f32(pblocks * 2 * out.C)
+                        ptrs += [C.ptr(t.act.t), C.ptr(t.act.g), C.ptr(part)]
+                        pooled[id(t.act)] = (part, pblocks)
+                    self._emit(C.OP_POOL_REDUCE, ints=(self.dtid, out.N, out.H, out.W, out.C, L), ptrs=ptrs)
                 for t, sh in zip(terms, shifts):
                     a = t.act
                     if t is paired[1]:
@@ -974,7 +1003,7 @@ class Plan(object):
                     if a.bn is not None and a.nuse == 1 and self.training:
                         # single consumer: fuse pooling + masks + BatchNorm backward
                         self._bn_backward(a, C.ptr(out.g), mask, sh, t.relu,
-                                          extra=paired[1].act if t is paired[0] else None)
+                                          extra=paired[1].act if t is paired[0] else None, pooled=pooled.get(id(a)))
                     else:
                         # accumulate d(post-activation value); BN backward runs at the producer
                         assert sh == 0

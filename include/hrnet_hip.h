@@ -81,6 +81,11 @@ enum {
                               mode}, p = {x0, w0 packed, bias, y, statistics, t1, t2, t3} */
   HR_OP_HEAD_BWD = 28,     /* hrnet_head_bwd: i = {dtype, N, H, W, K, Cout, mode, inner_relu}, p = {dY, wT, y, out, bn scale,
                               bn shift, coef} */
+  HR_OP_POOL_REDUCE = 29,  /* the BatchNorm-backward reduction of up to three nearest-up-sampled terms of one fuse sum
+                              (pose_hrnet.py:257-264) in ONE walk over the sum's gradient: i = {dtype, N, H, W, C,
+                              nlev}, p = {g, mask, y1, dz1, partials1, y2, dz2, partials2, y3, dz3, partials3}; level
+                              l pools 2^l x 2^l blocks; dz_l is stored for the apply pass (HR_OP_GRAD_TERM with g =
+                              dz_l, sh = 0); partials_l[hrnet_reduce_blocks(N, H / 2, W / 2, C)][2][C] */
   HR_OP_UPSAMPLE_T = 27    /* hrnet_upsample_bilinear_t: i = {dtype, N, H, W, C, nout, align, h1, w1, h2, w2, h3, w3,
                               streamed}, p = {G, out1, out2, out3} */
 };

@@ -304,6 +304,10 @@ def _written(op, C, plan=None):
         return [(op.p[3], True)]          # the head's raw output (its statistics feed a finalize launch)
     if k == C.OP_UPSAMPLE_T:
         return [(op.p[1 + j], True) for j in range(op.i[5])]
+    if k == C.OP_BN_BWD_REDUCE:
+        return [(op.p[6], True)] if op.p[6] else []           # the pooled, masked gradient kept for the apply pass
+    if k == C.OP_POOL_REDUCE:
+        return [(op.p[3 + 3 * l], True) for l in range(op.i[5])]
     if k == C.OP_HEAD_BWD:
         return [(op.p[3], op.i[6] == 2)]      # mode 1: statistics rows (a kept f32 tensor), mode 2: the gradient of raw y
     if k == C.OP_BN_FINALIZE:
