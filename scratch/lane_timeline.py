@@ -38,7 +38,7 @@ hm, _ = model(x); loss = crit(hm, gt); loss.backward()
 torch.cuda.synchronize()
 engine.Program.run = orig_run
 plan = net.plan(batch, 256, 256, True, True)
-KN = {1: 'conv', 2: 'wgrad', 5: 'sum', 6: 'grad_term', 7: 'bn_red', 8: 'bn_bfin', 9: 'cat', 10: 'cat_bwd', 11: 'im2col', 26: 'head_mix', 27: 'upsample_t', 12: 'to_nchw', 13: 'to_nhwc',
+KN = {1: 'conv', 2: 'wgrad', 5: 'sum', 6: 'grad_term', 7: 'bn_red', 8: 'bn_bfin', 9: 'cat', 10: 'cat_bwd', 11: 'im2col', 26: 'head_mix', 27: 'upsample_t', 28: 'head_bwd', 29: 'pool_red', 25: 'ew_table', 12: 'to_nchw', 13: 'to_nhwc',
       16: 'fill', 18: 'ev_rec', 19: 'ev_wait', 20: 'wred', 21: 'fused', 22: 'bn_fin_tab', 23: 'pw_fused', 24: 'conv_sum', 15: 'bias_grad'}
 for pname, prog in (('fwd', plan.fwd), ('bwd', plan.bwd)):
     lo, t = TIMED[id(prog)]
