@@ -6,6 +6,12 @@
 HR_DEFINE_CONV_LAUNCH(hr_conv_launch_generic, CONV_GENERIC)
 
 namespace {
+// workgroup -> pixel-walk mapping of the tile-walking bodies (conv_body.h): contiguous runs per XCD (HRNET_CONV_XCD=0:
+// consecutive walks on consecutive XCDs, as rounds 1-2)
+inline int conv_xcd_runs() {
+  static const int v = getenv("HRNET_CONV_XCD") ? atoi(getenv("HRNET_CONV_XCD")) : 1;
+  return v;
+}
 // which specialised body serves a launch (see conv_body.h)
 inline int conv_mode(const ConvArgs& a, bool in_relu) {
   if (a.bs_y) return CONV_BS;
@@ -145,6 +151,7 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   a.tpw = tc.tpw;
   a.gx = tc.gx;
   a.gy = (Cout + tc.bn - 1) / tc.bn;
+  a.xcd_runs = conv_xcd_runs();
   // the tile choice is keyed on the ORIGINAL stride so hrnet_conv_tiles() agrees; a upz conv
   // runs the stride-1 kernel with that tile
   ConvLaunch l;
@@ -197,6 +204,7 @@ int hr_launch_conv_sum(const HrOp& op, hipStream_t s) {
   a.tpw = tc.tpw;
   a.gx = tc.gx;
   a.gy = (Cout + tc.bn - 1) / tc.bn;
+  a.xcd_runs = conv_xcd_runs();
   ConvLaunch l;
   l.a = a; l.tc = tc; l.dtype = dtype; l.N = N; l.ks = ks; l.stride = 1;
   return hr_conv_launch_fwds(l, s);

@@ -48,6 +48,7 @@ struct ConvArgs {
   int Ho, Wo, Cout;
   int tiles_y, tiles_x, total_tiles, tpw;  // tpw = pixel tiles per workgroup
   int gx, gy;                              // pixel walks x output-channel blocks (1-D grid, see conv_body)
+  int xcd_runs;                            // workgroup -> walk mapping: 1 = every XCD takes a contiguous run of walks
   int in_relu, upz, accumulate;
   // input BatchNorm given as batch sums (hr_bn_from_sums) instead of scale/shift arrays: no finalize launch between
   // the producer and this conv. stats_atomic: this launch's own statistics go to sums[8][2][Cout] by float atomics
@@ -150,8 +151,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
   const int lg = lane >> 4;
   // 1-D grid, XCD-aware: workgroup ids round-robin over the 8 XCDs, so the gy output-channel blocks of one
   // pixel walk get ids 8 apart - the same XCD (they share its L2 for the input tile) and adjacent in time
+  // ... and (xcd_runs, round 3) every XCD takes ONE contiguous run of walks: logical index L = (id % 8) * (grid / 8) +
+  // id / 8, so neighbouring tiles (which share halo rows) meet in one L2 as well - with consecutive walks on
+  // consecutive XCDs every XCD fetched its neighbours' halo rows again (1.24 - 1.57x the algorithmic bytes)
   int wg_p, wg_nb;
-  if (a.gy == 1) {
+  if (a.xcd_runs) {
+    const int G8 = gridDim.x >> 3;
+    const int L = ((int)blockIdx.x & 7) * G8 + ((int)blockIdx.x >> 3);
+    wg_p = L / a.gy; wg_nb = L - wg_p * a.gy;
+  } else if (a.gy == 1) {
     wg_p = blockIdx.x; wg_nb = 0;
   } else {
     const int grp = blockIdx.x / (8 * a.gy), r = blockIdx.x % (8 * a.gy);
@@ -763,7 +771,7 @@ inline int conv_km(int dtype, int ks, int Cin, int tile_id) {
 template <int MODE, typename T, int KS, int STRIDE, int KM>
 int launch_km(const ConvArgs& a, const TileChoice& tc, hipStream_t s) {
   const int gy_ = (a.Cout + tc.bn - 1) / tc.bn;
-  dim3 grid((unsigned)(gy_ == 1 ? tc.gx : (tc.gx + 7) / 8 * 8 * gy_));
+  dim3 grid((unsigned)(a.xcd_runs ? (tc.gx * gy_ + 7) / 8 * 8 : (gy_ == 1 ? tc.gx : (tc.gx + 7) / 8 * 8 * gy_)));
   if constexpr (STRIDE == 4) {
     if (tc.id == 6) LAUNCH_CONV(T, 3, 4, 16, 16, 32, 4, 1, 1);
     else LAUNCH_CONV(T, 3, 4, 8, 16, 64, 2, 2, 1);
