@@ -130,10 +130,13 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   const int li = lane & 15, lg = lane >> 4;
   // workgroup -> (split, input-channel block): the ncb blocks of one split get ids 8 apart (same XCD: they
   // stage the same output-side tiles)
-  const int grp = blockIdx.x / (8 * a.ncb), r8 = blockIdx.x % (8 * a.ncb);
-  const int cb = r8 / 8;
-  const int split = grp * 8 + (r8 & 7);
-  if (split >= a.nsplit) return;
+  // ... and (round 3) every XCD takes a CONTIGUOUS run of splits: at each step of the walk the splits hold consecutive
+  // pixel tiles, whose halos overlap - they meet in one L2 instead of being fetched by two
+  const int S8 = (a.nsplit + 7) >> 3;                       // splits per XCD
+  const int xcd = (int)blockIdx.x & 7, j8 = (int)blockIdx.x >> 3;
+  const int cb = j8 % a.ncb;
+  const int split = xcd * S8 + j8 / a.ncb;
+  if (split >= a.nsplit || j8 / a.ncb >= S8) return;
   const int c0 = cb * CB;
   int stamp_i = 0;
 #ifdef HR_MEASURE

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  int b = blockIdx.x;
+  // (workgroup ids go round-robin over the 8 XCDs: logical index L gives every XCD a contiguous run of tiles, so
+  // neighbouring tiles - which stage overlapping low-resolution pixels - and the channel chunks of a tile share an L2)
+  int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  if (b >= a.N * a.tiles_y * a.tiles_x * a.chunks) return;
   const int chunk = b % a.chunks; b /= a.chunks;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
@@ -549,7 +552,9 @@ __global__ __launch_bounds__(256) void upsample_t_tile_kernel(UpTileArgs a) {
   constexpr int VEC = TT<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
+  // (every XCD takes a contiguous run of tiles: the halos of neighbouring tiles overlap by half the region)
+  int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  if (b >= a.N * a.tiles_y * a.tiles_x * a.chunks) return;
   const int chunk = b % a.chunks; b /= a.chunks;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
@@ -641,7 +646,7 @@ static int head_launch(HeadMixArgs& a, int dtype, int mode, hipStream_t s) {
     }
     attr_set = true;
   }
-  const dim3 grid((unsigned)(tiles * a.chunks));
+  const dim3 grid((unsigned)((tiles * a.chunks + 7) / 8 * 8));
   if (mode == 0) hipLaunchKernelGGL(head_mix_tile_kernel<0>, grid, dim3(256), (size_t)off, s, a);
   else if (mode == 1) hipLaunchKernelGGL(head_mix_tile_kernel<1>, grid, dim3(256), (size_t)off, s, a);
   else hipLaunchKernelGGL(head_mix_tile_kernel<2>, grid, dim3(256), (size_t)off, s, a);
@@ -711,7 +716,7 @@ int hr_upsample_t_tile(int dtype, const void* g, void* const* outs, const int* h
   a.chunks = (C / vec + 3) / 4;
   const int R = HM_T + 2 * halo;
   const size_t lds = (size_t)R * (R * UT_PXB + 16);
-  const long long blocks = (long long)N * a.tiles_y * a.tiles_x * a.chunks;
+  const long long blocks = ((long long)N * a.tiles_y * a.tiles_x * a.chunks + 7) / 8 * 8;
   if (blocks >= (1ll << 31)) return 1;
   if (dtype == HR_F32)
     hipLaunchKernelGGL(upsample_t_tile_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, a);
