@@ -48,6 +48,7 @@ struct BwdArgs {
   float* rows;           // optional [nsplit][2][Cin]
   float* slabs;          // [nsplit][Cout][9][Cin] f32
   int N, H, W, Cin, Cout;
+  unsigned g_bytes, a_bytes;   // bytes of the [N,H,W,Cout] / [N,H,W,Cin] tensors (buffer descriptors: 32-bit offsets)
   int tiles_y, tiles_x, total_tiles;
   int ncb, nsplit;
   int in_relu, mask_out;
@@ -111,10 +112,20 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   constexpr int GVECS = HPX * VPG, AVECS = HPX * VPA, WVECS = CB * 9 * VPG;
   constexpr int XG = (GVECS + NT - 1) / NT, XA = (AVECS + NT - 1) / NT, XW = (WVECS + NT - 1) / NT;
   constexpr int FCO = COP / 16;                // co fragments
-  constexpr int FCOW = FCO / WCO;              // ... per wave (weight gradient)
-  constexpr int NFR = 9 * (CB / 16);           // (tap, ci-fragment) outputs = 18
-  constexpr int NPW = (NFR + WN - 1) / WN;
-  static_assert(WCO * WN == NW && FCO % WCO == 0 && PW % 16 == 0, "wave grid");
+  // weight gradient: the (co-fragment, ci-fragment) blocks of dW[COP][9][CB] - nine 16x16 tiles each, one per tap - are
+  // dealt to the waves: BPW whole blocks per wave when there are at least as many blocks as waves, else the pixel
+  // (contraction) axis is split over KSPLIT groups of waves, each wave owning one block for every KSPLIT-th k-step; the
+  // groups' partial sums meet in LDS after the walk. Every wave issues the same 9 * BPW MFMAs per k-step (round 3's
+  // (tap, ci-fragment) lists were uneven - 3 / 2 per wave - and their `if (fr < NFR)` tests cut the phase into 24
+  // read -> wait -> 2 MFMA blocks per tile).
+  constexpr int NBLK = FCO * (CB / 16);
+  constexpr int KSPLIT = NBLK >= NW ? 1 : NW / NBLK;
+  constexpr int NWB = NW / KSPLIT;             // waves of one k-group
+  constexpr int BPW = NBLK / NWB;              // blocks per wave (consecutive co-fragments of one ci-fragment)
+  constexpr int NFR = 9 * (CB / 16);           // (tap, ci-fragment) outputs per co-fragment = 18
+  static_assert(WCO * WN == NW && PW % 16 == 0, "wave grid");
+  static_assert(NBLK % NWB == 0 && NW % KSPLIT == 0 && FCO % BPW == 0, "weight-gradient blocks per wave");
+  static_assert((BM / KSTEP) % KSPLIT == 0 && KSTEP % TW == 0, "k-steps per wave group; a k-step is whole tile rows");
   static_assert(NT % VPG == 0 && NT % VPA == 0, "a thread keeps one channel vector");
   constexpr int YBYTES = YLDS ? XG * NT * 16 : 0;   // one 16-byte slot per (thread, k): lane-linear
   constexpr int CBYTES = (3 * COP + 2 * CB) * 4;     // per-channel coefficient tables: A, B, C | scale, shift
@@ -223,49 +234,45 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   // the next tile's loads are issued in NS steps spread over the nine taps of the input-gradient loop instead of
   // in one burst: a burst of ~100 KB per CU stalls the issuing waves on the CU's miss queue (~2.5 us per tile
   // measured) and leaves the memory pipe idle during the matrix phases
-  const char *bz = nullptr, *by = nullptr, *bx = nullptr;   // wave-uniform bases of the tile being loaded
+  // Buffer loads: a lane outside the image (or a walk with no next tile) gets an offset beyond the descriptor's
+  // range - the hardware returns zeros and fetches nothing - so the prefetch is free of branches and sits inside the
+  // matrix phases without cutting them into scheduling regions (round 3 branched around every batch of loads).
+  constexpr unsigned OOB = 0x80000000u;
+  const auto rdz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)a.g_bytes, 0x00020000);
+  const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)(has_coef ? a.y : a.dz), 0, has_coef ? (int)a.g_bytes : 0, 0x00020000);
+  const auto rdx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.a_bytes, 0x00020000);
+  int tbg = 0, tba = 0;        // byte offset of the loaded tile's first halo pixel (may be negative: valid lanes add >= its magnitude)
   int liy0 = 0, lix0 = 0;
-  auto load_begin = [&](int t) {
+  bool lnext = false;
+  auto load_begin = [&](int t, bool valid) {
     int n, ty, tx;
-    tile_of(t, n, ty, tx);
+    tile_of(valid ? t : 0, n, ty, tx);
     n = __builtin_amdgcn_readfirstlane(n); ty = __builtin_amdgcn_readfirstlane(ty); tx = __builtin_amdgcn_readfirstlane(tx);
     liy0 = ty * TH - 1; lix0 = tx * TW - 1;
-    // (image n, halo origin); may point before the image (masked lanes never load)
-    bz = a.dz + (ptrdiff_t)n * a.H * rowG + (ptrdiff_t)liy0 * rowG + (ptrdiff_t)lix0 * pixG;
-    by = a.y + (ptrdiff_t)n * a.H * rowG + (ptrdiff_t)liy0 * rowG + (ptrdiff_t)lix0 * pixG;
-    bx = a.x + (ptrdiff_t)n * a.H * rowA + (ptrdiff_t)liy0 * rowA + (ptrdiff_t)lix0 * pixA;
+    tbg = (n * a.H + liy0) * rowG + lix0 * pixG;
+    tba = (n * a.H + liy0) * rowA + lix0 * pixA;
+    lnext = valid;
     okg = oka = 0;
   };
   auto load_g = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int gy = liy0 + (hyxg[k] >> 16), gx = lix0 + (hyxg[k] & 0xffff);
-    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    // branch-free: these loads are issued between the transposing LDS reads of the matrix phases, which need
-    // every lane active (ds_read_b64_tr_b16 is a cross-lane gather); lanes outside the image read the tensor's
-    // first bytes and are zeroed when the tile is staged
-    const int o = ok ? offg[k] : 0;
-    rz[k] = *(const V16*)((ok ? bz : a.dz) + o);
-    if (has_coef) {
-      if constexpr (YLDS) {
-        // destination = wave-uniform base + lane * 16: slot (tid + k*NT) of the y image
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((ok ? by : a.y) + o),
-                                         (__attribute__((address_space(3))) void*)(yl + ((tid & ~63) + k * NT) * 16),
-                                         16, 0, 0);
-      } else {
-        ry[k] = *(const V16*)((ok ? by : a.y) + o);
-      }
-    }
+    const bool ok = lnext && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    const unsigned vo = ok ? (unsigned)(tbg + offg[k]) : OOB;
+    rz[k] = __builtin_amdgcn_raw_buffer_load_b128(rdz, vo, 0, 0);
+    ry[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);   // (no coefficients: an empty descriptor, nothing is fetched)
     okg |= (ok ? 1u : 0u) << k;
   };
   auto load_a = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int gy = liy0 + (hyxa[k] >> 16), gx = lix0 + (hyxa[k] & 0xffff);
-    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    rx[k] = *(const V16*)((ok ? bx : a.x) + (ok ? offa[k] : 0));
+    const bool ok = lnext && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    rx[k] = __builtin_amdgcn_raw_buffer_load_b128(rdx, ok ? (unsigned)(tba + offa[k]) : OOB, 0, 0);
     oka |= (ok ? 1u : 0u) << k;
   };
   constexpr int NS = XG + XA;
-  constexpr int NSLOT = 9 + (BM / KSTEP <= 8 ? BM / KSTEP : 0);   // issue slots: the 9 taps (+ the weight-gradient k-steps)
+  constexpr int NKW = (BM / KSTEP) / KSPLIT;                       // weight-gradient k-steps of one wave
+  constexpr int NSLOT = 9 + (NKW <= 8 ? NKW : 0);                  // issue slots: the 9 taps (+ the weight-gradient k-steps)
   auto load_step = [&](auto sc) {       // step s < XG: dz + y vector s; else x vector s - XG
     constexpr int s_ = decltype(sc)::value;
     if constexpr (s_ < XG) load_g(std::integral_constant<int, s_>{});
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     }
   };
   auto load_tile = [&](int t) {         // all at once (the first tile)
-    load_begin(t);
+    load_begin(t, true);
     load_steps(std::integral_constant<int, 0>{}, std::integral_constant<int, (NS > 4 ? 4 : NS)>{});
     if constexpr (NS > 4) load_steps(std::integral_constant<int, 4>{}, std::integral_constant<int, (NS > 8 ? 8 : NS)>{});
     if constexpr (NS > 8) load_steps(std::integral_constant<int, 8>{}, std::integral_constant<int, (NS > 12 ? 12 : NS)>{});
@@ -362,13 +369,20 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     const int p = wave * PW + fp * 16 + li;
     boff[fp] = ((p / TW) * HALO + (p % TW)) * GPIX + lg * 16;
   }
-  // weight gradient: this wave's co fragments and (tap, ci-fragment) list
-  const int wco = wave % WCO, wn = wave / WCO;
-  f32x4 accw[NPW][FCOW];
+  // weight gradient: this wave's k-group and blocks (co-fragments cof0 .. cof0 + BPW - 1 of ci-fragment cif)
+  const int kh = wave / NWB, wb = wave % NWB;
+  const int cof0 = (wb * BPW) % FCO, cif = (wb * BPW) / FCO;
+  constexpr int KROWS = KSTEP / TW;            // tile rows one k-step spans
+  // LDS byte offsets of this lane group's first pixel in the wave's first k-step: g at the pixel itself (the centre
+  // of the halo image), a at its tap (0, 0) neighbour; later k-steps and taps add compile-time constants
+  const int wpl = lg * VEC;
+  const int wga = ((wpl / TW + kh * KROWS + 1) * HALO + wpl % TW + 1) * GPIX;
+  const int wgb = ((wpl / TW + kh * KROWS) * HALO + wpl % TW) * APIX;
+  f32x4 accw[BPW][9];
 #pragma unroll
-  for (int j = 0; j < NPW; ++j)
+  for (int q = 0; q < BPW; ++q)
 #pragma unroll
-    for (int f = 0; f < FCOW; ++f) accw[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < 9; ++tp) accw[q][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
@@ -376,6 +390,14 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   const int ci0 = c0 + lg * 8;             // this lane's 8 output channels of the input gradient
   const bool ci_ok = ci0 < a.Cin;
   constexpr int EV = 8 * ES / 16;          // 16-byte vectors of 8 channels: 1 (bf16) or 2 (f32)
+  // epilogue operands and the output through buffer descriptors too (an absent operand: an empty descriptor)
+  const auto rad = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend ? a.addend : a.x), 0, a.addend ? (int)a.a_bytes : 0, 0x00020000);
+  const auto rbs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bs_y ? a.bs_y : a.x), 0, a.bs_y ? (int)a.a_bytes : 0, 0x00020000);
+  const auto rdo = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, (int)a.a_bytes, 0x00020000);
+
+  // MFMAs / LDS-read instructions behind one fragment (sched_group_barrier counts)
+  constexpr int MF = ES == 2 ? 1 : 4;          // mma16<T>: one 16x16x32 bf16 MFMA or four 16x16x4 f32 ones
+  constexpr int RDF = ES == 2 ? 2 : 4;         // trl<T>: two ds_read_b64_tr_b16 or four ds_read_b32
 
   int t = split;
   if (t < a.total_tiles) load_tile(t);
@@ -388,98 +410,128 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     __syncthreads();
     FSTAMP();
     const bool has_next = t + a.nsplit < a.total_tiles && !HR_ABLATE(a, 8);
-    if (has_next) load_begin(t + a.nsplit);
+    load_begin(t + a.nsplit, has_next);
     int n, ty, tx;
     tile_of(t, n, ty, tx);
     n = __builtin_amdgcn_readfirstlane(n); ty = __builtin_amdgcn_readfirstlane(ty); tx = __builtin_amdgcn_readfirstlane(tx);
     // epilogue operands of this tile (addend, next BatchNorm's raw input), fetched before the matrix work
-    const size_t img = (size_t)n * a.H * rowA;
     V16 pa[FP][EV], pb[FP][EV];
     bool pok[FP];
-    int poff[FP];
+    unsigned poff[FP];
 #pragma unroll
     for (int fp = 0; fp < FP; ++fp) {
       const int p = wave * PW + fp * 16 + li;
       const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
       pok[fp] = ci_ok && oy < a.H && ox < a.W && !HR_ABLATE(a, 4);
-      poff[fp] = (oy * a.W + ox) * pixA + ci0 * ES;          // within image n
+      poff[fp] = pok[fp] ? (unsigned)(((n * a.H + oy) * a.W + ox) * pixA + ci0 * ES) : OOB;
 #pragma unroll
       for (int q = 0; q < EV; ++q) {
-        pa[fp][q] = v16_zero();
-        pb[fp][q] = v16_zero();
-        if (pok[fp]) {
-          if (a.addend) pa[fp][q] = *(const V16*)(a.addend + img + poff[fp] + q * 16);
-          if (a.bs_y) pb[fp][q] = *(const V16*)(a.bs_y + img + poff[fp] + q * 16);
-        }
+        pa[fp][q] = __builtin_amdgcn_raw_buffer_load_b128(rad, pok[fp] ? poff[fp] + q * 16 : OOB, 0, 0);
+        pb[fp][q] = __builtin_amdgcn_raw_buffer_load_b128(rbs, pok[fp] ? poff[fp] + q * 16 : OOB, 0, 0);
       }
     }
 
     FSTAMP();
-    // ---- input gradient: conv of g with the transposed, flipped kernel ----
+    // ---- input gradient: conv of g with the transposed, flipped kernel. Steps (tap, 32-channel k-chunk); the
+    // operands of step s + 1 are read from LDS before the MFMAs of step s are issued (two register sets) ----
     f32x4 accd[2][FP];
 #pragma unroll
     for (int fc = 0; fc < 2; ++fc)
 #pragma unroll
       for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!HR_ABLATE(a, 1))
+    {
+      constexpr int NKK = COP / KSTEP, NDS = 9 * NKK, KB = KSTEP * ES;
+      V16 daf[2][2], dbf[2][FP];
+      auto rd_d = [&](int s_, int buf) {
+        const int tp = s_ / NKK, kk = s_ % NKK;
+        const int tapb = ((tp / 3) * HALO + (tp % 3)) * GPIX;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int tapb = ((tp / 3) * HALO + (tp % 3)) * GPIX;
+        for (int fc = 0; fc < 2; ++fc) daf[buf][fc] = *(const V16*)(wl + aoff[fc] + (tp * COP) * ES + kk * KB);
 #pragma unroll
-      for (int kk = 0; kk < COP / KSTEP; ++kk) {
-        constexpr int KB = KSTEP * ES;
-        V16 af[2], bf[FP];
+        for (int fp = 0; fp < FP; ++fp) dbf[buf][fp] = *(const V16*)(gl + boff[fp] + tapb + kk * KB);
+      };
+      rd_d(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + FP, 0);      // (the pipeline's first reads are a group of their own)
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc) af[fc] = *(const V16*)(wl + aoff[fc] + (tp * COP) * ES + kk * KB);
+      for (int s_ = 0; s_ < NDS; ++s_) {
+        if (s_ + 1 < NDS) rd_d(s_ + 1, (s_ + 1) & 1);
+        if (!HR_ABLATE(a, 1)) {
 #pragma unroll
-        for (int fp = 0; fp < FP; ++fp) bf[fp] = *(const V16*)(gl + boff[fp] + tapb + kk * KB);
+          for (int fc = 0; fc < 2; ++fc)
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc)
-#pragma unroll
-          for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = mma16<T>(af[fc], bf[fp], accd[fc][fp]);
-      }
-      // this tap's share of the next tile's loads; vector-memory instructions may not move across (everything
-      // else may): the requests enter the memory pipe evenly while the matrix pipe works
-      __builtin_amdgcn_sched_barrier(0x38F);
-      if (has_next) {
-        switch (tp) {
+            for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = mma16<T>(daf[s_ & 1][fc], dbf[s_ & 1][fp], accd[fc][fp]);
+        }
+        if (s_ + 1 < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 2 + FP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * FP * MF, 0);
+        if ((s_ + 1) % NKK == 0) {
+          // this tap's share of the next tile's loads; vector-memory instructions may not move across (everything
+          // else may): the requests enter the memory pipe evenly while the matrix pipe works
+          __builtin_amdgcn_sched_barrier(0x38F);
+          switch (s_ / NKK) {
 #define LS(SL) case SL: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
-          LS(0) LS(1) LS(2) LS(3) LS(4) LS(5) LS(6) LS(7) LS(8)
+            LS(0) LS(1) LS(2) LS(3) LS(4) LS(5) LS(6) LS(7) LS(8)
 #undef LS
+          }
+          __builtin_amdgcn_sched_barrier(0x38F);
         }
       }
-      __builtin_amdgcn_sched_barrier(0x38F);
     }
 
     FSTAMP();
-    // ---- weight gradient: pixels are the contraction index; both operands come transposed out of the
-    // images staged above (center pixels of g, tap-shifted pixels of a) ----
+    // ---- weight gradient: pixels are the contraction index; both operands come transposed out of the images
+    // staged above (centre pixels of g, tap-shifted pixels of a). Steps (k-step, tap): one B fragment (a, this
+    // wave's ci-fragment) per step in a ring RB - 1 steps ahead of its MFMAs, the A fragments (g, the wave's
+    // co-fragments) of the next k-step half a k-step ahead ----
+    {
+      constexpr int NWS = NKW * 9, RB = 4;
+      V16 waf[2][BPW], wbf[RB];
+      auto rd_wa = [&](int i, int buf) {
 #pragma unroll
-    for (int ks = 0; ks < BM / KSTEP; ++ks) {
-      if constexpr (BM / KSTEP <= 8) {
-        if (has_next) {
-          switch (ks) {
-#define LS(SL) case SL - 9: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
-            LS(9) LS(10) LS(11) LS(12) LS(13) LS(14) LS(15) LS(16)
-#undef LS
-          }
+        for (int q = 0; q < BPW; ++q)
+          waf[buf][q] = trl<T>(gl, wga + i * (KSPLIT * KROWS * HALO * GPIX), GPIX, (cof0 + q) * 16 * ES, lane);
+      };
+      auto rd_wb = [&](int s_) {
+        const int i = s_ / 9, tp = s_ % 9;
+        wbf[s_ % RB] = trl<T>(al, wgb + i * (KSPLIT * KROWS * HALO * APIX) + ((tp / 3) * HALO + tp % 3) * APIX, APIX,
+                             cif * 16 * ES, lane);
+      };
+      rd_wa(0, 0);
+#pragma unroll
+      for (int s_ = 0; s_ < RB - 1; ++s_) rd_wb(s_);
+      __builtin_amdgcn_sched_group_barrier(0x100, (BPW + RB - 1) * RDF, 0);
+#pragma unroll
+      for (int s_ = 0; s_ < NWS; ++s_) {
+        const int i = s_ / 9, tp = s_ % 9;
+        if (s_ + RB - 1 < NWS) rd_wb(s_ + RB - 1);
+        if (tp == 4 && i + 1 < NKW) rd_wa(i + 1, (i + 1) & 1);
+        if (!HR_ABLATE(a, 2)) {
+#pragma unroll
+          for (int q = 0; q < BPW; ++q) accw[q][tp] = mma16<T>(waf[i & 1][q], wbf[s_ % RB], accw[q][tp]);
         }
-        __builtin_amdgcn_sched_barrier(0x38F);
-      }
-      const int p0 = ks * KSTEP + lg * VEC;
-      const int py = p0 / TW, px = p0 % TW;
-      const int gr0 = ((py + 1) * HALO + px + 1) * GPIX;
-      V16 af[FCOW];
-#pragma unroll
-      for (int f = 0; f < FCOW; ++f) af[f] = trl<T>(gl, gr0, GPIX, (wco * FCOW + f) * 16 * ES, lane);
-#pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        const int fr = wn + WN * j;
-        if (fr < NFR) {
-          const int tp = fr / (CB / 16), cf = fr % (CB / 16);
-          const V16 bf = trl<T>(al, ((py + tp / 3) * HALO + px + tp % 3) * APIX, APIX, cf * 16 * ES, lane);
-#pragma unroll
-          for (int f = 0; f < FCOW; ++f) accw[j][f] = mma16<T>(af[f], bf, accw[j][f]);
+        {
+          constexpr int dummy = 0; (void)dummy;
+          const int nrd = (s_ + RB - 1 < NWS ? RDF : 0) + ((tp == 4 && i + 1 < NKW) ? BPW * RDF : 0);
+          // (the counts are compile-time constants once the loop is unrolled; the builtin needs literals)
+          switch (nrd) {
+            case 2: __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); break;
+            case 4: __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); break;
+            case 6: __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); break;
+            case 8: __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); break;
+            case 12: __builtin_amdgcn_sched_group_barrier(0x100, 12, 0); break;
+            default: break;
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, BPW * MF, 0);
+        }
+        if constexpr (NKW <= 8) {
+          if (tp == 8) {
+            __builtin_amdgcn_sched_barrier(0x38F);
+            switch (i) {
+#define LS(SL) case SL - 9: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
+              LS(9) LS(10) LS(11) LS(12) LS(13) LS(14) LS(15) LS(16)
+#undef LS
+            }
+            __builtin_amdgcn_sched_barrier(0x38F);
+          }
         }
       }
     }
@@ -492,33 +544,33 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
       float v[8];
       v[0] = accd[0][fp].x; v[1] = accd[0][fp].y; v[2] = accd[0][fp].z; v[3] = accd[0][fp].w;
       v[4] = accd[1][fp].x; v[5] = accd[1][fp].y; v[6] = accd[1][fp].z; v[7] = accd[1][fp].w;
-      if (pok[fp]) {
-        if (a.addend) {
-          float ad[8];
+      {
+        float ad[8];               // (no addend: zeros out of the empty descriptor)
 #pragma unroll
-          for (int q = 0; q < EV; ++q) v16_unpack<T>(pa[fp][q], ad + q * VEC);
+        for (int q = 0; q < EV; ++q) v16_unpack<T>(pa[fp][q], ad + q * VEC);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += ad[k];
-        }
-        if (a.mask_out) {
-          float am[8];
-          const char* ap = al + ((p / TW + 1) * HALO + (p % TW) + 1) * APIX + lg * 8 * ES;
+        for (int k = 0; k < 8; ++k) v[k] += ad[k];
+      }
+      if (a.mask_out) {
+        float am[8];
+        const char* ap = al + ((p / TW + 1) * HALO + (p % TW) + 1) * APIX + lg * 8 * ES;
 #pragma unroll
-          for (int q = 0; q < EV; ++q) v16_unpack<T>(*(const V16*)(ap + q * 16), am + q * VEC);
+        for (int q = 0; q < EV; ++q) v16_unpack<T>(*(const V16*)(ap + q * 16), am + q * VEC);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = am[k] > 0.f ? v[k] : 0.f;
-        }
+        for (int k = 0; k < 8; ++k) v[k] = am[k] > 0.f ? v[k] : 0.f;
+      }
 #pragma unroll
-        for (int q = 0; q < EV; ++q) *(V16*)(a.dx + img + poff[fp] + q * 16) = v16_pack<T>(v + q * VEC);
-        if (a.rows) {
-          float yb[8];
+      for (int q = 0; q < EV; ++q)
+        __builtin_amdgcn_raw_buffer_store_b128(v16_pack<T>(v + q * VEC), rdo, pok[fp] ? poff[fp] + q * 16 : OOB, 0, 0);
+      if (a.rows) {
+        float yb[8];
 #pragma unroll
-          for (int q = 0; q < EV; ++q) v16_unpack<T>(pb[fp][q], yb + q * VEC);
+        for (int q = 0; q < EV; ++q) v16_unpack<T>(pb[fp][q], yb + q * VEC);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            s1[k] += v[k];
-            s2[k] = fmaf(v[k], yb[k], s2[k]);
-          }
+        for (int k = 0; k < 8; ++k) {
+          const float vv = pok[fp] ? v[k] : 0.f;
+          s1[k] += vv;
+          s2[k] = fmaf(vv, yb[k], s2[k]);
         }
       }
     }
@@ -553,26 +605,48 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   }
 
   FSTAMP();
+  // ---- the k-groups' partial weight gradients meet in LDS, in a fixed order: group 0 keeps the total ----
+  if constexpr (KSPLIT > 1) {
+    static_assert((KSPLIT - 1) * NWB * BPW * 9 * 1024 <= GBYTES + ABYTES + WBYTES, "k-group exchange fits the LDS images");
+    __syncthreads();          // (the statistics reduction above read its scratch in the same bytes)
+    f32x4* kl = (f32x4*)lds;  // [KSPLIT - 1][NWB][BPW * 9][64 lanes]
+    if (kh > 0) {
+#pragma unroll
+      for (int q = 0; q < BPW; ++q)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) kl[((((kh - 1) * NWB + wb) * BPW + q) * 9 + tp) * 64 + lane] = accw[q][tp];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int g = 1; g < KSPLIT; ++g)
+#pragma unroll
+        for (int q = 0; q < BPW; ++q)
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const f32x4 o = kl[((((g - 1) * NWB + wb) * BPW + q) * 9 + tp) * 64 + lane];
+            accw[q][tp] = f32x4{accw[q][tp].x + o.x, accw[q][tp].y + o.y, accw[q][tp].z + o.z, accw[q][tp].w + o.w};
+          }
+    }
+  }
+  const bool wwriter = kh == 0;
   // ---- weight-gradient slab of this workgroup: slab[split][co][tap][ci], D: col = ci, row = co ----
   if (a.atomic) {
     // [co][ci][tap] tiles of 16 output channels through LDS (the walk ended on a barrier: the images are free)
-    __syncthreads();          // (the statistics reduction above read its scratch in the same bytes)
+    __syncthreads();          // (the reductions above read their scratch in the same bytes)
     float* tl = (float*)lds;
     static_assert(16 * CB * 9 * 4 <= GBYTES + ABYTES + WBYTES, "weight-gradient tile fits the LDS images");
 #pragma unroll
-    for (int h = 0; h < COP / 16; ++h) {
+    for (int h = 0; h < FCO; ++h) {
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        const int fr = wn + WN * j;
-        if (fr < NFR) {
-          const int tp = fr / (CB / 16), cil = (fr % (CB / 16)) * 16 + li;
+      for (int q = 0; q < BPW; ++q) {
+        if (wwriter && cof0 + q == h) {
+          const int cil = cif * 16 + li;
 #pragma unroll
-          for (int f = 0; f < FCOW; ++f) {
-            if (wco * FCOW + f == h) {
-              const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
+          for (int tp = 0; tp < 9; ++tp) {
+            const float v4[4] = {accw[q][tp].x, accw[q][tp].y, accw[q][tp].z, accw[q][tp].w};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) tl[((lg * 4 + r) * CB + cil) * 9 + tp] = v4[r];
-            }
+            for (int r = 0; r < 4; ++r) tl[((lg * 4 + r) * CB + cil) * 9 + tp] = v4[r];
           }
         }
       }
@@ -583,25 +657,22 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
         const int co = h * 16 + col;
         if (co < a.Cout_real && rem < nci * 9) atomicAdd(a.slabs + ((size_t)co * a.Cin_real + c0) * 9 + rem, tl[idx]);
       }
-      if (h + 1 < COP / 16) __syncthreads();
+      if (h + 1 < FCO) __syncthreads();
     }
-  } else {
-  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+  } else if (wwriter) {
+    float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+    const int ci = c0 + cif * 16 + li;
 #pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int fr = wn + WN * j;
-    if (fr < NFR) {
-      const int tp = fr / (CB / 16), ci = c0 + (fr % (CB / 16)) * 16 + li;
+    for (int q = 0; q < BPW; ++q) {
+      const int co = (cof0 + q) * 16 + lg * 4;
 #pragma unroll
-      for (int f = 0; f < FCOW; ++f) {
-        const int co = (wco * FCOW + f) * 16 + lg * 4;
-        const float v4[4] = {accw[j][f].x, accw[j][f].y, accw[j][f].z, accw[j][f].w};
+      for (int tp = 0; tp < 9; ++tp) {
+        const float v4[4] = {accw[q][tp].x, accw[q][tp].y, accw[q][tp].z, accw[q][tp].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (co + r < a.Cout && ci < a.Cin) slab[((size_t)(co + r) * 9 + tp) * a.Cin + ci] = v4[r];
       }
     }
-  }
   }
   FSTAMP();
 }
@@ -723,7 +794,8 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
   HR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "bwd_fused: scale/shift must come together");
   HR_REQUIRE(!bs_y || rows, "bwd_fused: bs_y needs rows");
   HR_REQUIRE(N > 0 && H > 0 && W > 0, "bwd_fused: empty shape");
-  HR_REQUIRE((double)H * W * (Cin > Cout ? Cin : Cout) * 4.0 < 2147483648.0, "bwd_fused: one image exceeds 2 GiB");
+  HR_REQUIRE((double)N * H * W * (Cin > Cout ? Cin : Cout) * (dtype == HR_F32 ? 4.0 : 2.0) < 2147483648.0,
+             "bwd_fused: a tensor of 2 GiB or more (32-bit buffer offsets)");
   const FusedCfg c = fused_cfg(dtype, Cout);
   BwdArgs a;
   a.dz = (const char*)dz; a.y = (const char*)y; a.coef = ref ? nullptr : coef; a.x = (const char*)x;
@@ -731,6 +803,8 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
   a.in_scale = in_scale; a.in_shift = in_shift; a.wT = (const char*)wT; a.dx = (char*)dx;
   a.addend = (const char*)addend; a.bs_y = (const char*)bs_y; a.rows = rows; a.slabs = slabs;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.g_bytes = (unsigned)((size_t)N * H * W * Cout * (dtype == HR_F32 ? 4 : 2));
+  a.a_bytes = (unsigned)((size_t)N * H * W * Cin * (dtype == HR_F32 ? 4 : 2));
   a.tiles_y = (H + c.th - 1) / c.th; a.tiles_x = (W + 15) / 16; a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.ncb = (Cin + 31) / 32;
   a.nsplit = hrnet_bwd_fused_splits(dtype, N, H, W, Cin, Cout);

@@ -39,12 +39,12 @@ def stamped(N, H, W, Cc):
     st = buf.cpu().numpy().reshape(1024, 32)
     st = st[st[:, 0] != 0]
     nst = int((st[0] != 0).sum())
-    dl = np.diff(st[:, :nst], axis=1) / 100.0      # s_memtime ticks at 100 MHz -> us
-    names = ['weights', 'first loads', '|loop'] + ['top', 'store_tile', 'barrier', 'issue+prefetch', 'dgrad', 'wgrad', 'epilogue', 'barrier2'] * 8
-    print('workgroups', len(st), 'stamps', nst, 'lifetime median %.1f us' % float(np.median(st[:, nst - 1] - st[:, 0]) / 100.0))
+    dl = np.diff(st[:, :nst], axis=1)      # s_memtime ticks = shader cycles
+    names = ['weights', 'coef tables + first loads issued', 'loop entry'] + ['store_tile (waits for the loads)', 'barrier', 'epilogue operands issued', 'dgrad', 'wgrad', 'epilogue', 'barrier2 + loop'] * 8
+    print('workgroups', len(st), 'stamps', nst, 'lifetime median %.0f cycles' % float(np.median(st[:, nst - 1] - st[:, 0])))
     for k in range(nst - 1):
         nm = names[k] if k < len(names) else '?'
-        print('  %2d %-16s %.2f us' % (k, nm, float(np.median(dl[:, k]))))
+        print('  %2d %-34s %6.0f cycles' % (k, nm, float(np.median(dl[:, k]))))
 if os.environ.get('STAMP'):
     stamped(64, 64, 64, 32)
     stamped(64, 32, 32, 64)
