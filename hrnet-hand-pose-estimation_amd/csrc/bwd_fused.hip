@@ -88,6 +88,25 @@ __device__ __forceinline__ V16 trl<float>(const char* base, int r0, int rstep, i
              *(const uint32_t*)(p + 3 * rstep)};
 }
 
+// LDS images are pixel-major with unpadded rows of RB = 64 / 128 / 256 bytes; the 16-byte chunk c of row P is stored at
+// chunk position c ^ lds_swz<RB>(P). With it both access patterns of the two matrix phases are free of bank conflicts
+// (round 3's padded rows: 45 % of the LDS cycles of a launch were conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE):
+//   ds_read_b128 of 16 consecutive rows x one chunk per lane group (input-gradient operands; serviced in the lane
+//   groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...): the 16 rows of a group fall on 16 different 16-byte slots;
+//   ds_read_b64_tr_b16 of rows P..P+3 (lane group 0) and P+4..P+7 (lane group 1) x two chunks (weight-gradient operands;
+//   32-lane halves): the 8 rows x 32 bytes cover the 64 banks once.
+// P = the pixel's COLUMN in its halo row (every read above stays inside one row, and a row's start only shifts all of its
+// slots alike), so a tap's row shift never changes the swizzle: a lane keeps one LDS offset per column shift and every
+// other displacement is an instruction offset.
+// (SWZ = false - the f32 instantiation, whose one-float transposing reads would need an offset per pixel: rows padded by
+// 16 bytes as in round 3, no swizzle.)
+template <int RB, bool SWZ = true>
+__device__ __forceinline__ int lds_swz(int P) {
+  static_assert(!SWZ || RB == 64 || RB == 128 || RB == 256, "row bytes");
+  if constexpr (!SWZ) return 0;
+  return RB == 64 ? ((P >> 1) & 2) : RB == 128 ? (P & 6) : ((P & 7) << 1);
+}
+
 // COP: staged output-side channels (Cout padded to 32 or 64). WCO x WN = 8 waves over the weight-gradient
 // outputs: WCO co-halves x WN groups of (tap, ci-fragment).
 // YLDS: the raw conv output y of the NEXT tile is parked in LDS instead of registers while it is in flight
@@ -104,10 +123,13 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   constexpr int TW = 16, HALO = 18, HALO_H = TH + 2, HPX = HALO_H * HALO, BM = TH * TW;
   constexpr int PW = BM / NW, FP = PW / 16;    // input-gradient pixels / pixel fragments per wave
   constexpr int CB = 32;                       // input-side channels per workgroup
-  constexpr int GPIX = COP * ES + 16;          // padded pixel strides (bytes)
-  constexpr int APIX = CB * ES + 16;
-  constexpr int WROW = 9 * COP * ES + 16;      // one row = one input channel: [tap][co]
-  constexpr int GBYTES = HPX * GPIX, ABYTES = HPX * APIX, WBYTES = CB * WROW;
+  constexpr bool SWZ = ES == 2;                // bf16: swizzled images; f32: padded rows (lds_swz)
+  constexpr int HP = HALO;                     // halo row pitch of the LDS images in pixels
+  constexpr int RBG = COP * ES + (SWZ ? 0 : 16), RBA = CB * ES + (SWZ ? 0 : 16);   // row (pixel) bytes of the g and a images
+  constexpr int NKK = COP / KSTEP;             // 64-byte k-chunks of the output-side channels
+  // weights: [tap][k-chunk][input channel (row)][64 bytes = KSTEP output channels], rows swizzled like a 64-byte image
+  constexpr int GBYTES = HALO_H * HP * RBG, ABYTES = HALO_H * HP * RBA, WBYTES = 9 * NKK * CB * 64;
+  static_assert(KSTEP * ES == 64, "a k-chunk of the weight image is one 64-byte row");
   constexpr int VPG = COP / VEC, VPA = CB / VEC;     // 16-byte vectors per pixel
   constexpr int GVECS = HPX * VPG, AVECS = HPX * VPA, WVECS = CB * 9 * VPG;
   constexpr int XG = (GVECS + NT - 1) / NT, XA = (AVECS + NT - 1) / NT, XW = (WVECS + NT - 1) / NT;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
         const int co = v * VEC;
         V16 w = v16_zero();
         if (ci < a.Cin && co < a.Cout) w = *(const V16*)(a.wT + ((size_t)(ci * 9 + tp) * a.Cout + co) * ES);
-        *(V16*)(wl + q * WROW + (tp * COP) * ES + v * 16) = w;
+        *(V16*)(wl + ((tp * NKK + (v >> 2)) * CB + q) * 64 + (((v & 3) ^ lds_swz<64>(q)) << 4)) = w;
       }
     }
   }
@@ -216,12 +238,14 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   // per vector remain (the address is a wave-uniform base + a 32-bit lane offset)
   const int rowG = a.W * a.Cout * ES, pixG = a.Cout * ES, rowA = a.W * a.Cin * ES, pixA = a.Cin * ES;
   int hyxg[XG], offg[XG], hyxa[XA], offa[XA];
+  int lofg[XG], lofa[XA];                    // LDS byte offsets of the staged vectors (swizzled images)
 #pragma unroll
   for (int k = 0; k < XG; ++k) {
     const int pix = (tid + k * NT) / VPG;
     const int hy = pix / HALO, hx = pix - hy * HALO;
     hyxg[k] = (tid + k * NT) < GVECS && cg_ok ? (hy << 16) | hx : (0x4000 << 16);    // invalid: row far outside
     offg[k] = hy * rowG + hx * pixG + cg * ES;
+    lofg[k] = (hy * HP + hx) * RBG + ((vg ^ lds_swz<RBG, SWZ>(hx)) << 4);
   }
 #pragma unroll
   for (int k = 0; k < XA; ++k) {
@@ -229,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     const int hy = pix / HALO, hx = pix - hy * HALO;
     hyxa[k] = (tid + k * NT) < AVECS && ca_ok ? (hy << 16) | hx : (0x4000 << 16);
     offa[k] = hy * rowA + hx * pixA + ca * ES;
+    lofa[k] = (hy * HP + hx) * RBA + ((va ^ lds_swz<RBA, SWZ>(hx)) << 4);
   }
 
   // the next tile's loads are issued in NS steps spread over the nine taps of the input-gradient loop instead of
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 #pragma unroll
     for (int k = 0; k < XG; ++k) {
       const int idx = tid + k * NT;
-      if (idx < GVECS) *(V16*)(gl + (idx / VPG) * GPIX + vg * 16) = ((okg >> k) & 1u) ? rz[k] : v16_zero();
+      if (idx < GVECS) *(V16*)(gl + lofg[k]) = ((okg >> k) & 1u) ? rz[k] : v16_zero();
     }
     if (has_aff || in_relu) {
       float sc[VEC], sh[VEC];
@@ -354,20 +379,29 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 #pragma unroll
     for (int k = 0; k < XA; ++k) {
       const int idx = tid + k * NT;
-      if (idx < AVECS) *(V16*)(al + (idx / VPA) * APIX + va * 16) = ((oka >> k) & 1u) ? rx[k] : v16_zero();
+      if (idx < AVECS) *(V16*)(al + lofa[k]) = ((oka >> k) & 1u) ? rx[k] : v16_zero();
     }
   };
 
   // ---- per-lane operand offsets ----
   // input gradient D[ci 32][pixel 256]: a wave owns 32 pixels (2 fragments) x all 32 channels (2 fragments);
   // a lane ends up with 8 contiguous channels of one pixel per pixel fragment
-  int aoff[2], boff[FP];
+  int aoff[2], boff[FP][3][NKK], moff[FP][8 * ES / 16];
 #pragma unroll
-  for (int fc = 0; fc < 2; ++fc) aoff[fc] = (fc * 16 + li) * WROW + lg * 16;
+  for (int fc = 0; fc < 2; ++fc) aoff[fc] = (fc * 16 + li) * 64 + ((lg ^ lds_swz<64>(fc * 16 + li)) << 4);
 #pragma unroll
   for (int fp = 0; fp < FP; ++fp) {
     const int p = wave * PW + fp * 16 + li;
-    boff[fp] = ((p / TW) * HALO + (p % TW)) * GPIX + lg * 16;
+    const int Pb = (p / TW) * HP + (p % TW);          // halo slot of the pixel's tap (0, 0) neighbour
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+        boff[fp][dx][kk] = (Pb + dx) * RBG + (((kk * 4 + lg) ^ lds_swz<RBG, SWZ>(p % TW + dx)) << 4);
+    // the staged input a at the pixel itself, this lane's 8 channels (the ReLU mask of the epilogue)
+#pragma unroll
+    for (int q = 0; q < 8 * ES / 16; ++q)
+      moff[fp][q] = (Pb + HP + 1) * RBA + (((lg * (8 * ES / 16) + q) ^ lds_swz<RBA, SWZ>(p % TW + 1)) << 4);
   }
   // weight gradient: this wave's k-group and blocks (co-fragments cof0 .. cof0 + BPW - 1 of ci-fragment cif)
   const int kh = wave / NWB, wb = wave % NWB;
@@ -375,9 +409,37 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   constexpr int KROWS = KSTEP / TW;            // tile rows one k-step spans
   // LDS byte offsets of this lane group's first pixel in the wave's first k-step: g at the pixel itself (the centre
   // of the halo image), a at its tap (0, 0) neighbour; later k-steps and taps add compile-time constants
-  const int wpl = lg * VEC;
-  const int wga = ((wpl / TW + kh * KROWS + 1) * HALO + wpl % TW + 1) * GPIX;
-  const int wgb = ((wpl / TW + kh * KROWS) * HALO + wpl % TW) * APIX;
+  // bf16: lane group lg reads pixels 4 lg .. 4 lg + 3 of the k-step's first tile row (first transposing read) and of
+  // its second row (second read): the pairing of pixels with k indices is free as long as both operands use the same
+  // one, and this one keeps the 32-lane halves of a read on 8 consecutive halo slots (lds_swz). f32: 4 lg .. 4 lg + 3.
+  const int wq = (lane & 15) >> 2, wp4 = lane & 3;
+  const int wPA = (kh * KROWS + 1) * HP + 1 + 4 * lg + (ES == 2 ? wq : 0);   // g: the pixel itself (image centre)
+  const int wPB = (kh * KROWS) * HP + 4 * lg + (ES == 2 ? wq : 0);           // a: its tap (0, 0) neighbour
+  int wao[BPW], wbo[3];
+#pragma unroll
+  for (int q = 0; q < BPW; ++q)
+    wao[q] = wPA * RBG + ((((cof0 + q) * 2 + (wp4 >> 1)) ^ lds_swz<RBG, SWZ>(1 + 4 * lg + wq)) << 4) + (wp4 & 1) * 8;
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+    wbo[dx] = (wPB + dx) * RBA + (((cif * 2 + (wp4 >> 1)) ^ lds_swz<RBA, SWZ>(4 * lg + wq + dx)) << 4) + (wp4 & 1) * 8;
+  // one 16-channel x KSTEP-pixel fragment out of a swizzled image. bf16: `off` = wao / wbo entry + row displacement;
+  // f32: P0 = the lane group's first pixel (four one-float reads, the swizzle recomputed per pixel)
+  auto tr_frag = [&](const char* img, auto rbc, int off, int P0, int cfrag) -> V16 {
+    constexpr int RB = decltype(rbc)::value;
+    if constexpr (ES == 2) {
+      const LDS_AS char* l = (const LDS_AS char*)img;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + off));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + off + HP * RB));
+      const bf16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      return __builtin_bit_cast(V16, v);
+    } else {
+      uint32_t r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        r[j] = *(const uint32_t*)(img + (P0 + j) * RB + (((cfrag * 4 + (li >> 2)) ^ lds_swz<RB, SWZ>(P0 + j)) << 4) + (li & 3) * 4);
+      return V16{r[0], r[1], r[2], r[3]};
+    }
+  };
   f32x4 accw[BPW][9];
 #pragma unroll
   for (int q = 0; q < BPW; ++q)
@@ -440,28 +502,30 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
 #pragma unroll
       for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      constexpr int NKK = COP / KSTEP, NDS = 9 * NKK, KB = KSTEP * ES;
-      V16 daf[2][2], dbf[2][FP];
+      constexpr int NDS = 9 * NKK;
+      // (DPF steps ahead: an LDS read returns after ~150-200 cycles under eight reading waves, a step's MFMAs issue in 64)
+      constexpr int DPF = COP <= 32 ? 2 : 1, DNB = DPF + 1;
+      V16 daf[DNB][2], dbf[DNB][FP];
       auto rd_d = [&](int s_, int buf) {
         const int tp = s_ / NKK, kk = s_ % NKK;
-        const int tapb = ((tp / 3) * HALO + (tp % 3)) * GPIX;
 #pragma unroll
-        for (int fc = 0; fc < 2; ++fc) daf[buf][fc] = *(const V16*)(wl + aoff[fc] + (tp * COP) * ES + kk * KB);
+        for (int fc = 0; fc < 2; ++fc) daf[buf][fc] = *(const V16*)(wl + aoff[fc] + (tp * NKK + kk) * (CB * 64));
 #pragma unroll
-        for (int fp = 0; fp < FP; ++fp) dbf[buf][fp] = *(const V16*)(gl + boff[fp] + tapb + kk * KB);
+        for (int fp = 0; fp < FP; ++fp) dbf[buf][fp] = *(const V16*)(gl + boff[fp][tp % 3][kk] + (tp / 3) * (HP * RBG));
       };
-      rd_d(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + FP, 0);      // (the pipeline's first reads are a group of their own)
+#pragma unroll
+      for (int s_ = 0; s_ < DPF; ++s_) rd_d(s_, s_ % DNB);
+      __builtin_amdgcn_sched_group_barrier(0x100, DPF * (2 + FP), 0);      // (the pipeline's first reads are a group of their own)
 #pragma unroll
       for (int s_ = 0; s_ < NDS; ++s_) {
-        if (s_ + 1 < NDS) rd_d(s_ + 1, (s_ + 1) & 1);
+        if (s_ + DPF < NDS) rd_d(s_ + DPF, (s_ + DPF) % DNB);
         if (!HR_ABLATE(a, 1)) {
 #pragma unroll
           for (int fc = 0; fc < 2; ++fc)
 #pragma unroll
-            for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = mma16<T>(daf[s_ & 1][fc], dbf[s_ & 1][fp], accd[fc][fp]);
+            for (int fp = 0; fp < FP; ++fp) accd[fc][fp] = mma16<T>(daf[s_ % DNB][fc], dbf[s_ % DNB][fp], accd[fc][fp]);
         }
-        if (s_ + 1 < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 2 + FP, 0);
+        if (s_ + DPF < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 2 + FP, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * FP * MF, 0);
         if ((s_ + 1) % NKK == 0) {
           // this tap's share of the next tile's loads; vector-memory instructions may not move across (everything
@@ -483,17 +547,18 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
     // wave's ci-fragment) per step in a ring RB - 1 steps ahead of its MFMAs, the A fragments (g, the wave's
     // co-fragments) of the next k-step half a k-step ahead ----
     {
-      constexpr int NWS = NKW * 9, RB = 4;
+      constexpr int NWS = NKW * 9, RB = COP <= 32 ? 8 : 6;
       V16 waf[2][BPW], wbf[RB];
       auto rd_wa = [&](int i, int buf) {
 #pragma unroll
         for (int q = 0; q < BPW; ++q)
-          waf[buf][q] = trl<T>(gl, wga + i * (KSPLIT * KROWS * HALO * GPIX), GPIX, (cof0 + q) * 16 * ES, lane);
+          waf[buf][q] = tr_frag(gl, std::integral_constant<int, RBG>{}, wao[q] + i * (KSPLIT * KROWS * HP * RBG),
+                                wPA + i * (KSPLIT * KROWS * HP), cof0 + q);
       };
       auto rd_wb = [&](int s_) {
         const int i = s_ / 9, tp = s_ % 9;
-        wbf[s_ % RB] = trl<T>(al, wgb + i * (KSPLIT * KROWS * HALO * APIX) + ((tp / 3) * HALO + tp % 3) * APIX, APIX,
-                             cif * 16 * ES, lane);
+        wbf[s_ % RB] = tr_frag(al, std::integral_constant<int, RBA>{}, wbo[tp % 3] + (i * KSPLIT * KROWS + tp / 3) * (HP * RBA),
+                              wPB + (i * KSPLIT * KROWS + tp / 3) * HP + tp % 3, cif);
       };
       rd_wa(0, 0);
 #pragma unroll
@@ -514,6 +579,8 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
           // (the counts are compile-time constants once the loop is unrolled; the builtin needs literals)
           switch (nrd) {
             case 2: __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); break;
+            case 10: __builtin_amdgcn_sched_group_barrier(0x100, 10, 0); break;
+            case 16: __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); break;
             case 4: __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); break;
             case 6: __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); break;
             case 8: __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); break;
@@ -553,9 +620,8 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
       }
       if (a.mask_out) {
         float am[8];
-        const char* ap = al + ((p / TW + 1) * HALO + (p % TW) + 1) * APIX + lg * 8 * ES;
 #pragma unroll
-        for (int q = 0; q < EV; ++q) v16_unpack<T>(*(const V16*)(ap + q * 16), am + q * VEC);
+        for (int q = 0; q < EV; ++q) v16_unpack<T>(*(const V16*)(al + moff[fp][q]), am + q * VEC);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = am[k] > 0.f ? v[k] : 0.f;
       }
@@ -683,14 +749,16 @@ struct FusedCfg {
 
 // Variant: 0 = 16x16 tiles, 8 waves, one workgroup per CU; 1 = 16x16 tiles, 4 waves, two per CU;
 // 2 = 8x16 tiles, 4 waves, two or three per CU. (HRNET_FUSED_VARIANT overrides the default for measurements.)
-inline int fused_variant() {
+inline int fused_variant(int cop) {
   static const int v = getenv("HRNET_FUSED_VARIANT") ? atoi(getenv("HRNET_FUSED_VARIANT")) : -1;
-  return v;
+  static const int v32 = getenv("HRNET_FUSED_V32") ? atoi(getenv("HRNET_FUSED_V32")) : v;
+  static const int v64 = getenv("HRNET_FUSED_V64") ? atoi(getenv("HRNET_FUSED_V64")) : v;
+  return cop <= 32 ? v32 : v64;
 }
 
 inline FusedCfg fused_cfg(int dtype, int Cout) {
   // 0 in .cop = shape not served by the fused kernel (LDS: 160 KB per CU)
-  const int var = fused_variant();
+  const int var = fused_variant(Cout <= 32 ? 32 : 64);
   if (dtype == HR_F32) return Cout <= 32 ? FusedCfg{32, 16, 8, 1, 8, 0, 1} : FusedCfg{0, 0, 0, 0, 0, 0, 0};
   if (Cout <= 32) {
     if (var == 1) return FusedCfg{32, 16, 4, 1, 4, 0, 2};
@@ -736,7 +804,7 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   static const int cus32 = getenv("HRNET_FUSED_CUS32") ? atoi(getenv("HRNET_FUSED_CUS32")) : cus;
   static const int cus64 = getenv("HRNET_FUSED_CUS64") ? atoi(getenv("HRNET_FUSED_CUS64")) : cus;
   const int small = c.cop == 32 ? cus32 : cus64;
-  int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb >= 2048 ? big : small) * c.per_cu / ncb;
+  int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb * c.th >= 2048 * 16 ? big : small) * c.per_cu / ncb;
   if (ns < 1) ns = 1;
   if (ns > tiles) ns = tiles;
   // even walks: every split takes the same number of tiles when possible

@@ -28,6 +28,7 @@ struct WgradArgs {
   const float* in_shift;
   float* slabs;
   int N, H, W, Cin, Ho, Wo, Cout;
+  unsigned x_bytes, dy_bytes;   // bytes of the two operand tensors (buffer descriptors: 32-bit offsets)
   int tiles_y, tiles_x, total_tiles;
   int in_relu;
   // atomic = 1: `slabs` IS the OIHW f32 gradient [Cout_real][Cin_real][ks][ks]; every workgroup ADDS its tile into it
@@ -65,15 +66,28 @@ __device__ __forceinline__ V16 tr_load<float>(const char* base, int r0, int rste
              *(const uint32_t*)(p + 3 * rstep)};
 }
 
+// XOR swizzle of the 16-byte chunk index of a pixel-major LDS image with unpadded RB-byte rows, keyed on the pixel's
+// COLUMN c in its image row (bwd_fused.hip: lds_swz): ds_read_b64_tr_b16 of eight consecutive pixels of a row - the
+// 32-lane halves of a transposing read below - covers the 64 banks once. f32 (one-float transposing reads): rows padded
+// by 16 bytes, no swizzle.
+template <int RB, bool SWZ>
+__device__ __forceinline__ int wg_swz(int c) {
+  static_assert(!SWZ || RB == 64 || RB == 128 || RB == 256, "row bytes");
+  if constexpr (!SWZ) return 0;
+  return RB == 64 ? ((c >> 1) & 2) : RB == 128 ? (c & 6) : ((c & 7) << 1);
+}
+
 template <typename T, int KS, int STRIDE, int TH, int TW, int BCO, int KC, int WCO, int WN>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   constexpr int VEC = TT<T>::VEC;
   constexpr int KSTEP = TT<T>::KSTEP;
+  constexpr int ES = (int)sizeof(T);
   constexpr int TAPS = KS * KS;
   constexpr int HALO_H = (TH - 1) * STRIDE + KS;
   constexpr int HALO_W = (TW - 1) * STRIDE + KS;
-  constexpr int PIXB = KC * (int)sizeof(T) + 16;
-  constexpr int DYB = BCO * (int)sizeof(T) + 16;
+  constexpr bool SWZ = ES == 2;
+  constexpr int PIXB = KC * ES + (SWZ ? 0 : 16);      // row (pixel) bytes of the x image
+  constexpr int DYB = BCO * ES + (SWZ ? 0 : 16);      // ... of the dY image
   constexpr int XBYTES = HALO_H * HALO_W * PIXB;
   constexpr int BM = TH * TW;
   constexpr int FCO = BCO / 16, FCI = KC / 16;
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   constexpr int DVPP = BCO / VEC;            // 16-byte vectors per dY pixel
   static_assert(WCO * WN == 4 && FCO % WCO == 0, "wave grid");
   static_assert(BM % KSTEP == 0 && TW % VEC == 0, "pixel groups stay inside a tile row");
+  static_assert(TW == 16 || TW == 8, "a k-step is two rows of 16 or four rows of 8 pixels");
   constexpr int LDSTOT = (XBYTES + BM * DYB) > 16 * KC * TAPS * 4 ? (XBYTES + BM * DYB) : 16 * KC * TAPS * 4;
   __shared__ __attribute__((aligned(16))) char lds[LDSTOT];
   char* xl = lds;
@@ -94,72 +109,77 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int co0 = blockIdx.y * BCO, c0 = blockIdx.z * KC;
   constexpr int PAD = KS / 2;
 
-  // this wave's (tap, ci-fragment) list
-  int tapb[NPW], cib[NPW];
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int f = wn + WN * j;
-    const int t = f / FCI, fci = f % FCI;
-    tapb[j] = ((t / KS) * HALO_W + (t % KS)) * PIXB;
-    cib[j] = fci * 16 * (int)sizeof(T);
-  }
-
   f32x4 acc[NPW][FCOW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
 #pragma unroll
     for (int f = 0; f < FCOW; ++f) acc[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging registers: the next tile's loads are issued before the MFMAs of the current one
-  // and written to LDS after them (issue-early / write-late) ----
+  // ---- staging registers: the next tile's loads are issued before the MFMAs of the current one and written to LDS
+  // after them (issue-early / write-late). Buffer loads: a vector outside the tensor (or a walk with no next tile)
+  // gets an offset beyond the descriptor's range - zeros come back, nothing is fetched, and no branch cuts the loop ----
   constexpr int VPP = KC / VEC;                          // 16-byte vectors per halo pixel
   constexpr int XVECS = HALO_H * HALO_W * VPP, DVECS = BM * DVPP;
   constexpr int XV = (XVECS + 255) / 256, DV = (DVECS + 255) / 256;
-  static_assert(256 % VPP == 0 && XV <= 31, "staging layout");
+  static_assert(256 % VPP == 0 && 256 % DVPP == 0 && XV <= 31, "staging layout");
+  constexpr unsigned OOB = 0x80000000u;
+  const auto rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
   V16 xr[XV], dr[DV];
   unsigned xok = 0;
-  const int xv = tid % VPP;
+  const int xv = tid % VPP, dv = tid % DVPP;
   const int xc = c0 + xv * VEC;
-  const bool xcvalid = xc < a.Cin;
+  const bool xcvalid = xc < a.Cin, dcvalid = co0 + dv * VEC < a.Cout;
   const bool has_affine = a.in_scale != nullptr;
   float sc[VEC], sh[VEC];
-  if (has_affine && xcvalid) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      sc[j] = a.in_scale[xc + j];
-      sh[j] = a.in_shift[xc + j];
-    }
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = (has_affine && xcvalid) ? a.in_scale[xc + j] : 1.f;
+    sh[j] = (has_affine && xcvalid) ? a.in_shift[xc + j] : 0.f;
+  }
+  // per-thread staging geometry (the same for every tile): halo coordinates, global byte offset from the tile's first
+  // halo pixel, LDS byte offset in the (swizzled) image
+  int xhy[XV], xgo[XV], xlo[XV], dpy[DV], dgo[DV], dlo[DV];
+  const int pixX = a.Cin * ES, rowX = a.W * pixX, pixD = a.Cout * ES, rowD = a.Wo * pixD;
+#pragma unroll
+  for (int k = 0; k < XV; ++k) {
+    const int idx = tid + k * 256;
+    const int pix = idx / VPP, hy = pix / HALO_W, hx = pix - hy * HALO_W;
+    xhy[k] = (idx < XVECS && xcvalid) ? (hy << 16) | hx : (0x4000 << 16);
+    xgo[k] = hy * rowX + hx * pixX + xc * ES;
+    xlo[k] = pix * PIXB + ((xv ^ wg_swz<PIXB, SWZ>(hx)) << 4);
+  }
+#pragma unroll
+  for (int k = 0; k < DV; ++k) {
+    const int idx = tid + k * 256;
+    const int p = idx / DVPP, py = p / TW, px = p - py * TW;
+    dpy[k] = (idx < DVECS && dcvalid) ? (py << 16) | px : (0x4000 << 16);
+    dgo[k] = py * rowD + px * pixD + (co0 + dv * VEC) * ES;
+    dlo[k] = p * DYB + ((dv ^ wg_swz<DYB, SWZ>(px)) << 4);
   }
 
-  auto load_tile = [&](int tile) {
-    int b = tile;
+  auto load_tile = [&](int tile, bool valid) {
+    int b = valid ? tile : 0;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
     const int ty = b % a.tiles_y;
     const int n = b / a.tiles_y;
     const int iy0 = ty * TH * STRIDE - PAD, ix0 = tx * TW * STRIDE - PAD;
+    const int xb = (n * a.H + iy0) * rowX + ix0 * pixX;          // may be negative: valid lanes add at least its magnitude
+    const int db = (n * a.Ho + ty * TH) * rowD + tx * TW * pixD;
     xok = 0;
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
-      const int idx = tid + k * 256;
-      const int pix = idx / VPP;
-      const int gy = iy0 + pix / HALO_W, gx = ix0 + pix % HALO_W;
-      const bool ok = idx < XVECS && xcvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      xr[k] = v16_zero();
-      if (ok) {
-        xr[k] = *(const V16*)(a.x + ((size_t)((n * a.H + gy) * a.W + gx) * a.Cin + xc) * sizeof(T));
-        xok |= 1u << k;
-      }
+      const int gy = iy0 + (xhy[k] >> 16), gx = ix0 + (xhy[k] & 0xffff);
+      const bool ok = valid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx_, ok ? (unsigned)(xb + xgo[k]) : OOB, 0, 0);
+      xok |= (ok ? 1u : 0u) << k;
     }
 #pragma unroll
     for (int k = 0; k < DV; ++k) {
-      const int idx = tid + k * 256;
-      const int p = idx / DVPP, v = idx % DVPP;
-      const int oy = ty * TH + p / TW, ox = tx * TW + p % TW;
-      const int co = co0 + v * VEC;
-      dr[k] = v16_zero();
-      if (idx < DVECS && oy < a.Ho && ox < a.Wo && co < a.Cout)
-        dr[k] = *(const V16*)(a.dy + ((size_t)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * sizeof(T));
+      const int oy = ty * TH + (dpy[k] >> 16), ox = tx * TW + (dpy[k] & 0xffff);
+      const bool ok = valid && oy < a.Ho && ox < a.Wo;
+      dr[k] = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? (unsigned)(db + dgo[k]) : OOB, 0, 0);
     }
   };
   auto store_tile = [&]() {
@@ -168,47 +188,128 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       const int idx = tid + k * 256;
       if (idx < XVECS) {
         V16 val = xr[k];
-        if (((xok >> k) & 1u) && (has_affine || a.in_relu)) {
+        if (has_affine || a.in_relu) {
           float f[VEC];
           v16_unpack<T>(val, f);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            if (has_affine) f[j] = fmaf(f[j], sc[j], sh[j]);
+            f[j] = fmaf(f[j], sc[j], sh[j]);
             if (a.in_relu) f[j] = fmaxf(f[j], 0.f);
           }
-          val = v16_pack<T>(f);
+          val = ((xok >> k) & 1u) ? v16_pack<T>(f) : v16_zero();   // zero padding is applied AFTER the transform
         }
-        *(V16*)(xl + (idx / VPP) * PIXB + xv * 16) = val;
+        *(V16*)(xl + xlo[k]) = val;
       }
     }
 #pragma unroll
     for (int k = 0; k < DV; ++k) {
       const int idx = tid + k * 256;
-      if (idx < DVECS) *(V16*)(dl + (idx / DVPP) * DYB + (idx % DVPP) * 16) = dr[k];
+      if (idx < DVECS) *(V16*)(dl + dlo[k]) = dr[k];
     }
   };
 
+  // ---- per-lane offsets of the transposing operand reads (bf16). Lane group lg of a k-step reads four consecutive
+  // pixels of a tile row - columns 4 lg .. 4 lg + 3 of the k-step's first row (16-pixel rows; 8-pixel rows: row lg / 2,
+  // columns 4 (lg & 1) ..) with its first read, the same columns ROWS2 rows below with its second: which pixel carries
+  // which k index is free as long as both operands agree, and this pairing keeps the 32-lane halves of a read on eight
+  // consecutive pixels of one row (wg_swz). Displacements by k-step, tap row and fragment are instruction offsets.
+  constexpr int KROWS = KSTEP / TW;            // tile rows of a k-step: 2 (or 4, or 1 / 2 in f32)
+  constexpr int ROWS2 = TW == 16 ? 1 : 2;      // rows between a lane's two reads
+  const int wq = (lane & 15) >> 2, wp4 = lane & 3;
+  const int lrow = TW == 16 ? 0 : (lg >> 1), lcol = (TW == 16 ? 4 * lg : 4 * (lg & 1)) + (SWZ ? wq : 0);
+  int wao[FCOW], wbo[KS][FCI];
+#pragma unroll
+  for (int f = 0; f < FCOW; ++f)
+    wao[f] = (lrow * TW + lcol) * DYB + ((((wco * FCOW + f) * 2 + (wp4 >> 1)) ^ wg_swz<DYB, SWZ>(lcol)) << 4) + (wp4 & 1) * 8;
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+    for (int cf = 0; cf < FCI; ++cf)
+      wbo[dx][cf] = (lrow * STRIDE * HALO_W + lcol * STRIDE + dx) * PIXB +
+                    (((cf * 2 + (wp4 >> 1)) ^ wg_swz<PIXB, SWZ>(lcol * STRIDE + dx)) << 4) + (wp4 & 1) * 8;
+  // one 16-channel x KSTEP-pixel fragment; bf16: `off` = table entry + displacement, the second read `hi` bytes below;
+  // f32: four one-float reads of pixels P0, P0 + pstep, ... (padded rows, no swizzle)
+  auto tr_frag = [&](const char* img, int off, int hi, int f32_off, int f32_step) -> V16 {
+    if constexpr (SWZ) {
+      const LDS_AS char* l = (const LDS_AS char*)img;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + off));
+      const bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(l + off + hi));
+      const bf16x8 v = {lo.x, lo.y, lo.z, lo.w, h2.x, h2.y, h2.z, h2.w};
+      return __builtin_bit_cast(V16, v);
+    } else {
+      const char* p = img + f32_off + li * 4;
+      return V16{*(const uint32_t*)p, *(const uint32_t*)(p + f32_step), *(const uint32_t*)(p + 2 * f32_step),
+                 *(const uint32_t*)(p + 3 * f32_step)};
+    }
+  };
+  constexpr int MF = ES == 2 ? 1 : 4, RDF = ES == 2 ? 2 : 4;   // MFMAs / LDS reads behind one fragment
+  // this wave's (tap, ci-fragment) list: offsets of its B fragments at k-step 0 (an uneven list repeats the wave's first
+  // fragment in the missing position; that accumulator is dropped)
+  int boj[NPW], bfj[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    int fr = wn + WN * j;
+    if (fr >= NFR) fr = wn;
+    const int t = fr / FCI, cf = fr % FCI, ty_ = t / KS, tx_ = t % KS;
+    int base = 0;
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+      for (int c = 0; c < FCI; ++c)
+        if (dx == tx_ && c == cf) base = wbo[dx][c];
+    boj[j] = base + ty_ * HALO_W * PIXB;
+    const int pl = lg * VEC;                         // f32: first pixel of the lane group within a k-step
+    bfj[j] = (((pl / TW) * STRIDE + ty_) * HALO_W + (pl % TW) * STRIDE + tx_) * PIXB + cf * 16 * ES;
+  }
+
   int tile = blockIdx.x;
-  if (tile < a.total_tiles) load_tile(tile);
+  if (tile < a.total_tiles) load_tile(tile, true);
   for (; tile < a.total_tiles; tile += gridDim.x) {
     store_tile();
     __syncthreads();
-    if (tile + (int)gridDim.x < a.total_tiles) load_tile(tile + gridDim.x);  // in flight during the MFMAs
-#pragma unroll 2
-    for (int ks = 0; ks < BM / KSTEP; ++ks) {
-      const int p0 = ks * KSTEP + lg * VEC;  // first pixel of this lane group
-      const int py = p0 / TW, px = p0 % TW;
-      const int xr0 = ((py * STRIDE) * HALO_W + px * STRIDE) * PIXB;
-      V16 af[FCOW];
+    load_tile(tile + gridDim.x, tile + (int)gridDim.x < a.total_tiles);  // in flight during the MFMAs
+    // ---- steps (k-step, fragment j of this wave's (tap, ci-fragment) list): the B fragment of step s + RB - 1 is read
+    // before the MFMAs of step s are issued; the A fragments of the next k-step half a k-step ahead ----
+    {
+      constexpr int NKS = BM / KSTEP, NST = NKS * NPW, RB = NPW >= 4 ? 4 : NPW + 1;
+      V16 waf[2][FCOW], wbf[RB];
+      auto rd_a = [&](int ks, int buf) {
 #pragma unroll
-      for (int f = 0; f < FCOW; ++f)
-        af[f] = tr_load<T>(dl, p0 * DYB, DYB, (wco * FCOW + f) * 16 * (int)sizeof(T), lane);
+        for (int f = 0; f < FCOW; ++f)
+          waf[buf][f] = tr_frag(dl, wao[f] + ks * (KSTEP * DYB), ROWS2 * TW * DYB,
+                                (ks * KSTEP + lg * VEC) * DYB + (wco * FCOW + f) * 16 * ES, DYB);
+      };
+      auto rd_bb = [&](int s_) {
+        const int ks = s_ / NPW, j = s_ % NPW;
+        wbf[s_ % RB] = tr_frag(xl, boj[j] + ks * (KROWS * STRIDE * HALO_W * PIXB), ROWS2 * STRIDE * HALO_W * PIXB,
+                              bfj[j] + ks * ((KSTEP / TW) * STRIDE * HALO_W * PIXB), STRIDE * PIXB);
+      };
+      rd_a(0, 0);
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        if (wn + WN * j < NFR) {
-          const V16 bf = tr_load<T>(xl, xr0 + tapb[j], STRIDE * PIXB, cib[j], lane);
+      for (int s_ = 0; s_ < RB - 1 && s_ < NST; ++s_) rd_bb(s_);
+      __builtin_amdgcn_sched_group_barrier(0x100, (FCOW + RB - 1) * RDF, 0);
 #pragma unroll
-          for (int f = 0; f < FCOW; ++f) acc[j][f] = mma16<T>(af[f], bf, acc[j][f]);
+      for (int s_ = 0; s_ < NST; ++s_) {
+        const int ks = s_ / NPW, j = s_ % NPW;
+        if (s_ + RB - 1 < NST) rd_bb(s_ + RB - 1);
+        if (j == NPW / 2 && ks + 1 < NKS) rd_a(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int f = 0; f < FCOW; ++f) acc[j][f] = mma16<T>(waf[ks & 1][f], wbf[s_ % RB], acc[j][f]);
+        {
+          const int nrd = (s_ + RB - 1 < NST ? RDF : 0) + ((j == NPW / 2 && ks + 1 < NKS) ? FCOW * RDF : 0);
+          switch (nrd) {
+            case 2: __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); break;
+            case 4: __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); break;
+            case 6: __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); break;
+            case 8: __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); break;
+            case 10: __builtin_amdgcn_sched_group_barrier(0x100, 10, 0); break;
+            case 12: __builtin_amdgcn_sched_group_barrier(0x100, 12, 0); break;
+            case 16: __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); break;
+            case 18: __builtin_amdgcn_sched_group_barrier(0x100, 18, 0); break;
+            case 20: __builtin_amdgcn_sched_group_barrier(0x100, 20, 0); break;
+            default: break;
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, FCOW * MF, 0);
         }
       }
     }
@@ -393,6 +494,11 @@ int hr_launch_wgrad(const HrOp& op, hipStream_t s) {
   a.in_shift = (const float*)op.p[3];
   a.slabs = (float*)op.p[4];
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  const double es_ = dtype == HR_F32 ? 4.0 : 2.0;
+  HR_REQUIRE((double)N * H * W * Cin * es_ < 2147483648.0 && (double)N * Ho * Wo * Cout * es_ < 2147483648.0,
+             "wgrad: an operand tensor of 2 GiB or more (32-bit buffer offsets)");
+  a.x_bytes = (unsigned)((double)N * H * W * Cin * es_);
+  a.dy_bytes = (unsigned)((double)N * Ho * Wo * Cout * es_);
   a.tiles_y = (Ho + c.th - 1) / c.th;
   a.tiles_x = (Wo + c.tw - 1) / c.tw;
   a.total_tiles = N * a.tiles_y * a.tiles_x;
