@@ -17,10 +17,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-I', os.path.join(REPO, 'include'), '-I', CSRC, '-Wno-unused-result']
 
 
-# per-file extra flags. conv_ring.hip: no SLP vectorisation - the v_pk_fma_f32 / v_pk_add_f32 pairs it forms out of
-# the epilogue's scalar f32 arithmetic returned wrong sums for the last 16 lanes of a wave now and then (backward
-# statistics, run-to-run different), and packed f32 next to MFMAs is slower anyway (MI355X_MICROARCH.md)
-EXTRA = {'conv_ring.hip': ['-fno-slp-vectorize'], 'head_mix.hip': ['-fno-slp-vectorize']}
+# per-file extra flags (none at present). Round 3 compiled conv_ring.hip and head_mix.hip with -fno-slp-vectorize to
+# hide wrong backward-statistics rows; the cause was an LDS store-data hazard in the statistics epilogue, now pinned
+# in source (common.h: hr_pin / hr_lds_stores_done; DESIGN section 4, trap 4).
+EXTRA = {}
 
 
 def _stamp(src):

@@ -29,7 +29,8 @@ int hr_check_launch(const char* what) {
 }
 
 extern "C" const char* hrnet_last_error_string(void) { return g_err; }
-extern "C" int hrnet_abi_version(void) { return 1; }
+// 2: HR_OP_CONV i[17] (route), HR_OP_WGRAD i[12..15], HrPackEnt.ld, the head / table op kinds of round 3
+extern "C" int hrnet_abi_version(void) { return 2; }
 
 static int run_one(const HrOp& op, hipStream_t s, int k) {
   int e;

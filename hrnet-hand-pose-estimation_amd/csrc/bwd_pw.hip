@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
         s1[k] = wave_sum16(s1[k]);
         s2[k] = wave_sum16(s2[k]);
       }
+      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int j = 0; j < NG; ++j)
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
             sl[(wave * 2 + 0) * CI + j * 32 + lg * 8 + k] = s1[j * 8 + k];
             sl[(wave * 2 + 1) * CI + j * 32 + lg * 8 + k] = s2[j * 8 + k];
           }
+        hr_lds_stores_done();
       }
       __syncthreads();
       if (tid < 2 * CI) {

@@ -64,6 +64,15 @@ extern "C" int hrnet_conv_rows_bwdstats(int dtype, int N, int Ho, int Wo, int Ci
   return hrnet_conv_tiles_bwdstats(N, Ho, Wo, Cout, ks, stride);
 }
 
+// Which kernel family a recorded backward-statistics launch is bound to (HrOp.i[17] of HR_OP_CONV): 2 = the LDS-ring
+// pipeline, 1 = the tile-walking body. A plan sizes the launch's rows buffer (and the finalize launch's row count) from
+// hrnet_conv_rows_bwdstats when it is recorded; hrnet_conv_ring_enable() is a process-wide run-time switch, so the
+// op carries the decision and hr_launch_conv() follows it - or fails - instead of deciding again (0: decide at launch,
+// the direct C-ABI entry points).
+extern "C" int hrnet_conv_route(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride) {
+  return (ks == 3 && stride == 1 && hr_conv_ring_enabled() && hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout, 1)) ? 2 : 1;
+}
+
 // the tile walk a conv launch of this shape takes: out5 = {tile height, tile width, output-channel block,
 // pixel tiles per workgroup, pixel walks}; returns the number of pixel tiles (tests assert that the
 // multi-tile walk, tiles-per-workgroup >= 2, is what they exercise)
@@ -124,7 +133,12 @@ int hr_launch_conv(const HrOp& op, hipStream_t s) {
   HR_REQUIRE(!a.in_sums || mode == CONV_FWD || mode == CONV_FWDB,
              "conv2d: batch-sum input needs a forward launch that writes statistics or adds a bias");
   // the branch 3x3 convolutions: LDS-ring pipeline (conv_ring.hip)
-  if (ring_serves(a, dtype, ks, op.i[9], mode, op.i[11] != 0)) return launch_ring(a, op.i[11], s);
+  const int route = op.i[17];
+  HR_REQUIRE(route >= 0 && route <= 2, "conv2d: bad route %d", route);
+  const int rs = route == 1 ? 0 : ring_serves(a, dtype, ks, op.i[9], mode, op.i[11] != 0);
+  HR_REQUIRE(route != 2 || rs, "conv2d: the op was recorded for the LDS-ring kernel, which does not serve it now "
+             "(hrnet_conv_ring_enable() changed after the plan was recorded: record the plan again)");
+  if (rs) return launch_ring(a, op.i[11], s);
   // the GEMM-shaped head layer (and its input gradient): every output channel of a pixel block in one workgroup
   if (ks == 1 && stride == 1 && !upz && !a.accumulate && !a.bs_y && !a.in_scale && !a.in_sums && !op.i[11] &&
       (!a.stats || a.stats_atomic) && !a.in_dy && !a.in_dx && hr_gemm_pw_supported(dtype, Cin, Cout))

@@ -656,6 +656,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
       s1[k] = wave_sum16(s1[k]);
       s2[k] = wave_sum16(s2[k]);
     }
+    hr_pin(s1); hr_pin(s2);
     if (li == 0) {
 #pragma unroll
       for (int k = 0; k < C::LANE_C; ++k) {
@@ -663,6 +664,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         sl[(wp * 2 + 0) * BN + cl] = s1[k];
         sl[(wp * 2 + 1) * BN + cl] = s2[k];
       }
+      hr_lds_stores_done();
     }
     __syncthreads();
     if (tid < 2 * BN) {

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
       s1[k] = wave_sum16(s1[k]);
       s2[k] = wave_sum16(s2[k]);
     }
+    hr_pin(s1); hr_pin(s2);
     if (li == 0) {
 #pragma unroll
       for (int k = 0; k < C::LANE_C; ++k) {
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
         sl[(wpx * 2 + 0) * NB + cl] = s1[k];
         sl[(wpx * 2 + 1) * NB + cl] = s2[k];
       }
+      hr_lds_stores_done();
     }
     lds_barrier();
     if (tid < 2 * NB) {
@@ -572,10 +574,25 @@ struct RingPlan {
 // workgroups of (one image, 32 channels) pulls 75 MB of weights through the CUs' load paths for a 6 MB layer.
 int g_ring_enabled = -1;
 inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs);
+// bytes of one ring slot's input image per instantiation (RingCfg::XSB), checked against the kernels below
+constexpr int ring_xsb(int id) {
+  return id == 1 ? RingCfg<16, 16, 1, 32, 4, 4, 3, 1>::XSB : id == 2 ? RingCfg<8, 16, 1, 32, 4, 4, 3, 2>::XSB
+       : id == 3 ? RingCfg<16, 16, 1, 64, 8, 4, 2, 0>::XSB : id == 4 ? RingCfg<8, 8, 4, 64, 8, 4, 2, 0>::XSB
+       : id == 5 ? RingCfg<8, 8, 2, 64, 8, 4, 2, 0>::XSB : id == 6 ? RingCfg<16, 16, 2, 64, 8, 4, 2, 0>::XSB : 0;
+}
+// The prologue stages the input BatchNorm's [8][2][Cin] batch sums and gamma | beta in the LAST ring slot (whole
+// 1 KiB pieces): a launch whose staging image is larger than a slot would spill into weight slot 0 while other waves
+// direct-load it. Such shapes (Cin > 256 on the 16x16 / two-image instantiations: w48's widest branch on 512x512
+// inputs) are not served - the tile-walking body takes them.
+constexpr int ring_stage_bytes(int Cin) { return ((Cin * 64 + 1023) & ~1023) + ((Cin * 8 + 1023) & ~1023); }
+static_assert(ring_stage_bytes(32) <= ring_xsb(1) && ring_stage_bytes(64) <= ring_xsb(2), "resident-weight instantiations");
+static_assert(ring_stage_bytes(HR_RING_MAXC) <= ring_xsb(4) && ring_stage_bytes(HR_RING_MAXC) <= ring_xsb(6), "4 x 8x8 / 2 x 16x16 images");
+static_assert(ring_stage_bytes(256) <= ring_xsb(3) && ring_stage_bytes(256) <= ring_xsb(5), "w32's widest branch");
 inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
   // (measurement: HRNET_RING_IDS = bit mask of the instantiations that may be chosen)
   static const int ids = getenv("HRNET_RING_IDS") ? atoi(getenv("HRNET_RING_IDS")) : 0x7e;
   const RingPlan p = ring_plan_all(N, H, W, Cin, Cout, bs);
+  if (!bs && p.id && ring_stage_bytes(Cin) > ring_xsb(p.id)) return RingPlan{0, 0, 0, 0, 0, 0};
   return ((ids >> p.id) & 1) ? p : RingPlan{0, 0, 0, 0, 0, 0};
 }
 inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs) {

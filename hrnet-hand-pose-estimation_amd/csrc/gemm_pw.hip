@@ -144,12 +144,14 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
         s1[c] = wave_sum16(s1[c]);
         s2[c] = wave_sum16(s2[c]);
       }
+      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           sl[(wp * 2 + 0) * G_BN + n0 + c] = s1[c];
           sl[(wp * 2 + 1) * G_BN + n0 + c] = s2[c];
         }
+        hr_lds_stores_done();
       }
     }
   }

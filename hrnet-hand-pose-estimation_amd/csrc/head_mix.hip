@@ -340,12 +340,14 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
         s1[c] = wave_sum16(s1[c]);
         s2[c] = wave_sum16(s2[c]);
       }
+      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           sl[(wave * 2 + 0) * HM_CH + sb * 32 + lg * 8 + c] = s1[c];
           sl[(wave * 2 + 1) * HM_CH + sb * 32 + lg * 8 + c] = s2[c];
         }
+        hr_lds_stores_done();
       }
     }
   }

@@ -31,6 +31,7 @@ OP_UPSAMPLE_T = 27
 OP_HEAD_BWD = 28
 OP_POOL_REDUCE = 29
 LANE_SLOT = 18
+ABI_VERSION = 2      # hrnet_abi_version() of the library this file binds (HrOp slot meanings, table structs)
 
 
 class HrPackEnt(ctypes.Structure):
@@ -86,6 +87,7 @@ _SIGS = {
     'hrnet_conv_ring_enable': [_c_int],
     'hrnet_conv_ring_supported': [_c_int] * 6,
     'hrnet_conv_rows_bwdstats': [_c_int] * 8,
+    'hrnet_conv_route': [_c_int] * 8,
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_tiles_bwdstats': [_c_int] * 6,
     'hrnet_conv_tile_walk': [_c_int] * 8 + [_ip],
@@ -148,7 +150,7 @@ _SIGS = {
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_route', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks',
           'hrnet_head_mix_rows', 'hrnet_head_mix_supported'}
@@ -174,6 +176,9 @@ def lib():
         l.hrnet_last_error_string.restype = ctypes.c_char_p
         l.hrnet_event_create.argtypes = []
         l.hrnet_event_create.restype = ctypes.c_void_p
+        if l.hrnet_abi_version() != ABI_VERSION:
+            raise RuntimeError('{} has ABI version {}, this host code needs {}: rebuild it with `python '
+                               '__graft_entry__.py`'.format(LIB_PATH, l.hrnet_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

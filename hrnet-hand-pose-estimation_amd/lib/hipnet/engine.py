@@ -1159,9 +1159,12 @@ class Plan(object):
                             # x closes a block whose backward is a fused launch: this (last) contribution stores the
                             # gradient already multiplied by x's ReLU mask - no separate mask pass over the tensor
                             store_masked = 1
+                    # (a backward-statistics launch is bound to the kernel family its rows buffer was sized for)
+                    route = (C.call('hrnet_conv_route', self.dtid, x.N, x.H, x.W, y.C, x.C, ks, stride)
+                             if target is not None else 0)
                     self.bwd.add(C.OP_CONV,
                                  ints=(self.dtid, y.N, y.H, y.W, y.C, x.H, x.W, x.C, ks, stride,
-                                       1 if stride == 2 else 0, 0, 1 if x.ginit else 0, 0, store_masked),
+                                       1 if stride == 2 else 0, 0, 1 if x.ginit else 0, 0, store_masked, 0, 0, route),
                                  ptrs=ptrs)
                     x.ginit = True
                     if store_masked:

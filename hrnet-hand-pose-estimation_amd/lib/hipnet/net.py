@@ -62,6 +62,16 @@ class HipNet(object):
     def grad_of(self, p):
         return self._gview[id(p)]
 
+    def layout(self):
+        """[(parameter name, flat offset, numel)] of the trainable parameters, in flat order (FlatAdam tags its
+        checkpoints with it)"""
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        return [(names[id(p)],) + self.offsets[id(p)] for p in self.params if p.requires_grad]
+
+    def param_order(self):
+        """parameter names in module order (the flat order of checkpoints written before the late region existed)"""
+        return [n for n, _p in self.module.named_parameters()]
+
     @staticmethod
     def _is_late(name, p):
         """conv weights of a HighResolutionModule's wide branches (index >= 2) and fuse layers (see _flatten)"""

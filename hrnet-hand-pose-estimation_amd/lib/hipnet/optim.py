@@ -50,16 +50,56 @@ class FlatAdam(object):
         net.mark_weights_dirty()
 
     def state_dict(self):
-        self._state()            # the moment buffers are created lazily: a checkpoint before the first step has zeros
+        """the moments are flat tensors in the order of HipNet's flat buffer ([main | late | frozen], net._flatten);
+        `layout` = [(parameter name, offset, numel)] says which slice belongs to which parameter, so that a checkpoint
+        written under another flat order is re-mapped by name on load instead of landing on the wrong parameters"""
+        net = self._state()      # the moment buffers are created lazily: a checkpoint before the first step has zeros
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
-                'param_groups': self.param_groups}
+                'param_groups': self.param_groups, 'layout': net.layout()}
 
     def load_state_dict(self, sd):
-        self._state()
+        net = self._state()
+        cur = net.layout()
+        saved = sd.get('layout')
+        if saved is None:
+            # a checkpoint written before the flat buffer was re-ordered: trainable parameters in module order
+            saved = legacy_layout(cur, net.param_order())
         self.step_count = sd['step']
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.exp_avg.copy_(remap_flat(sd['exp_avg'], saved, cur, self.exp_avg.numel()))
+        self.exp_avg_sq.copy_(remap_flat(sd['exp_avg_sq'], saved, cur, self.exp_avg_sq.numel()))
         self.param_groups = sd['param_groups']
+
+
+def legacy_layout(cur_layout, module_order):
+    """[(name, offset, numel)] of the flat order used before the [main | late | frozen] permutation: the trainable
+    parameters in module (named_parameters) order, frozen ones behind them (they carry no moments)"""
+    size = {name: n for name, _o, n in cur_layout}
+    out, off = [], 0
+    for name in module_order:
+        if name in size:
+            out.append((name, off, size[name]))
+            off += size[name]
+    return out
+
+
+def remap_flat(saved, saved_layout, cur_layout, cur_numel):
+    """flat per-parameter state `saved` (laid out as saved_layout) re-ordered into cur_layout; refuses a checkpoint
+    whose parameter names or sizes differ from this model's"""
+    saved_layout = [(str(a), int(b), int(c)) for a, b, c in saved_layout]
+    cur_layout = [(str(a), int(b), int(c)) for a, b, c in cur_layout]
+    if saved_layout == cur_layout and saved.numel() == cur_numel:
+        return saved
+    smap = {name: (off, n) for name, off, n in saved_layout}
+    if set(smap) != {name for name, _o, _n in cur_layout}:
+        missing = sorted({name for name, _o, _n in cur_layout} ^ set(smap))[:5]
+        raise ValueError('optimizer checkpoint does not match this model (parameter names differ: {} ...)'.format(missing))
+    out = saved.new_zeros(cur_numel)
+    for name, off, n in cur_layout:
+        so, sn = smap[name]
+        if sn != n or so + sn > saved.numel():
+            raise ValueError('optimizer checkpoint does not match this model ({}: {} vs {} elements)'.format(name, sn, n))
+        out[off:off + n] = saved[so:so + sn]
+    return out
 
 
 class GradSync(object):

@@ -182,6 +182,10 @@ int hrnet_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout)
 /* statistics rows hrnet_conv2d_bwdstats leaves for a launch of this shape (hrnet_conv_tiles_bwdstats() for the
  * tile-walking body; the pixel walks of the LDS-ring grid where that serves the launch) */
 int hrnet_conv_rows_bwdstats(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride);
+/* kernel family a RECORDED backward-statistics launch of this shape is bound to (HR_OP_CONV i[17]): 2 = LDS ring,
+ * 1 = tile-walking body; the rows buffer above is sized for that family, so the op keeps the decision and a later
+ * hrnet_conv_ring_enable() cannot change how many rows the launch writes (it fails instead). 0 = decide at launch. */
+int hrnet_conv_route(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride);
 
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,

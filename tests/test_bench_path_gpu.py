@@ -253,6 +253,78 @@ def test_w48_bf16_training_step_tracks_fp32_device_path():
     assert cos >= 0.2, cos
 
 
+def test_config2_fp32_eval_b64_slice_matches_the_oracle():
+    """BASELINE config 2 at its FULL size: pose_hrnet_w32 256x256 fp32 forward-only inference at batch 64
+    on the device, arg-max decode; images 0-3 and the last image of that run against the CPU oracle's eval forward
+    (reference lib/models/pose_hrnet.py:511-568 with running statistics) - heat maps / inter_feat <= 1e-3 max-abs
+    (the north star's tolerance), decoded key points identical wherever the oracle's top two values differ by more
+    than the tolerance. An eval forward is per-image independent, so a slice of the B=64 run IS the B=5 run."""
+    from hipnet import synth
+    from oracle import hrnet_cpu as O
+    from utils.heatmap_decoding import get_final_preds
+    # the reference fixture's calibrated BatchNorm statistics (tests/golden/make_golden.py: running stats := batch stats
+    # of a calibration batch on the salt-0 weights), so that eval activations are O(1) and 1e-3 is a max-abs bound
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'w32_eval_b1.npz'))
+    _, sd = _model('fp32', salt=0)
+    for k in g.files:
+        if k.startswith('stat.'):
+            sd[k[5:]] = torch.from_numpy(g[k])
+    model, sd = _model('fp32', sd)
+    model.eval()
+    batch = synth.rhd_batch(64, seed=99)
+    x = torch.from_numpy(batch['imgs'])
+    with torch.no_grad():
+        hm, inter = model(x.cuda())
+        kp = get_final_preds(hm, use_softmax=False).cpu()
+    assert hm.shape == (64, 21, 64, 64) and inter.shape == (64, 32, 64, 64)
+    pick = [0, 1, 2, 3, 63]
+    with torch.no_grad():
+        ref_hm, ref_inter, _ = O.hrnet_forward({k: v.clone() for k, v in sd.items()}, O.W32_EXTRA, x[pick], training=False)
+    err = (hm.cpu()[pick] - ref_hm).abs().max().item()
+    ierr = (inter.cpu()[pick] - ref_inter).abs().max().item()
+    print('config 2 (B=64 fp32 eval) vs oracle on images {}: heat-map max-abs {:.2e}, inter_feat {:.2e}'.format(pick, err, ierr))
+    assert err <= 1e-3 and ierr <= 1e-3, (err, ierr)
+    assert ref_hm.abs().max().item() < 1e3        # (calibrated: the bound above is a real max-abs bound)
+    ref_kp = O.get_final_preds(ref_hm, use_softmax=False)
+    top2 = ref_hm.reshape(len(pick), 21, -1).topk(2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2e-3
+    assert clear.float().mean().item() > 0.5
+    assert torch.equal(kp[pick][clear], ref_kp[clear])
+    # nothing of the batch is left unwritten or shared between images
+    assert torch.isfinite(hm).all() and (hm[4:63].flatten(1).std(dim=1) > 0).all()
+
+
+def test_w48_config4_full_size_bf16_step_tracks_fp32_device_path():
+    """BASELINE config 4 at its FULL size: pose_hrnet_w48 384x288, batch 32, one bf16 training step (forward,
+    HeatmapLoss, backward) against the fp32 device path on the same batch and weights (the fp32 path is held to the
+    oracle in test_model_gpu.py / above): loss within 1e-2 relative, heat maps and gradients inside the whole-network
+    bf16 band measured on the 192x160 case, every gradient finite and non-zero (96x72 maps: tiles overhang on both
+    axes, 48 / 96 / 192 / 384-channel instantiations, the K = 48 head)."""
+    from hipnet import synth
+    m32, sd = _model('fp32', salt=8, yaml=YAML48, init='reference')
+    batch = synth.rhd_batch(32, seed=23, img_h=384, img_w=288)
+    hm32, _, loss32, g32 = _hip_step(m32, batch)
+    del m32
+    torch.cuda.empty_cache()
+    m16, _ = _model('bf16', sd, yaml=YAML48)
+    hm16, _, loss16, g16 = _hip_step(m16, batch)
+    assert hm16.shape == (32, 21, 96, 72)
+    rel = ((hm16.double() - hm32.double()).norm() / hm32.double().norm()).item()
+    cos = _cos(g16, g32)
+    print('w48 384x288 B=32 bf16 vs fp32 device path: heat-map rel L2 {:.4f}, loss {:.5f} / {:.5f}, grad cosine {:.5f}'.format(
+        rel, loss16, loss32, cos))
+    assert abs(loss16 - loss32) <= 1e-2 * abs(loss32)
+    assert rel <= 0.45, rel
+    assert cos >= 0.2, cos
+    for k, g in g16.items():
+        assert torch.isfinite(g).all(), k
+    dead = [k for k, g in g16.items() if g.abs().max().item() == 0.0 and g32[k].abs().max().item() > 0.0]
+    assert not dead, dead[:5]
+    # per-image heat maps: no image of the batch falls out of the band (a broken tile walk hits single images)
+    per_img = ((hm16.double() - hm32.double()).flatten(1).norm(dim=1) / hm32.double().flatten(1).norm(dim=1))
+    assert per_img.max().item() <= 0.6, per_img.max().item()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # bf16 fidelity, op by op, with exact inputs ("teacher forcing")
 # ---------------------------------------------------------------------------------------------------------

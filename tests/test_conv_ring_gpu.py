@@ -59,6 +59,7 @@ FWD_CASES = [
     (5, 8, 8, 256, 256, 'sums'),       # multi-image tiles: the last tile holds one image of four
     (6, 8, 8, 128, 192, 'arrays'),     # w48-like channel counts (three output-channel blocks)
     (64, 8, 8, 256, 256, 'raw'),       # the benchmark's fourth branch
+    (3, 8, 8, 384, 384, 'sums'),       # w48's widest branch: the 27 KB staging image of its BatchNorm sums fits the 40 KB slot
 ]
 
 
@@ -133,6 +134,40 @@ def test_ring_forward_matches_cpu_and_the_tile_walking_body(case):
         assert float((st1[0] - ref_s1).abs().max()) <= (2 * TOL + 1e-5) * scale1
         assert hh.rel_err(st1[1], ref_s2) <= 5 * TOL
         assert float((st1 - st0).abs().max() / st0.abs().max()) <= (1e-5 if H != 8 else 2e-3)
+
+
+def test_ring_declines_shapes_whose_batchnorm_staging_does_not_fit_a_slot():
+    """The prologue stages [8][2][Cin] batch sums + gamma | beta in the last ring slot: 27 KB for Cin = 384, more than the
+    20.7 KB slot of the 16x16-tile instantiation - such a launch used to spill into weight slot 0. The planner now leaves
+    it to the tile-walking body (and the launch through the dispatcher stays correct)."""
+    hh, C = _h(), _C()
+    C.call('hrnet_conv_ring_enable', 2)
+    assert C.call('hrnet_conv_ring_supported', 1, 2, 16, 16, 384, 384) == 0
+    assert C.call('hrnet_conv_ring_supported', 1, 2, 16, 16, 256, 256) > 0
+    assert C.call('hrnet_conv_ring_supported', 1, 2, 8, 8, 384, 384) > 0
+    N, H, W, Cc = 2, 16, 16, 384
+    g = torch.Generator().manual_seed(5)
+    x = _q(torch.randn(N, Cc, H, W, generator=g))
+    w = _q(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(Cc * 9))
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) - 0.5
+    s1, s2 = x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))
+    sums = torch.zeros(8, 2, Cc)
+    sums[3, 0], sums[3, 1] = s1.float(), s2.float()
+    cnt = float(N * H * W)
+    mean = s1 / cnt
+    invstd = 1.0 / torch.sqrt((s2 / cnt - mean * mean).clamp_min(0).float() + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean.float() * scale
+    ref = F.conv2d(_q(F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))), w, None, stride=1, padding=1)
+    wp, _, _ = hh.pack_weights(w, DT)
+    xd, gb, sd = hh.nhwc(x, DT), torch.cat([gamma, beta]).to(hh.DEV).contiguous(), sums.to(hh.DEV)
+    y = torch.full((N, H, W, Cc), float('nan'), dtype=DT, device=hh.DEV)
+    st = torch.zeros(8, 2, Cc, dtype=torch.float32, device=hh.DEV)
+    C.call('hrnet_conv2d_bnref', 1, xd.data_ptr(), wp.data_ptr(), sd.data_ptr(), gb.data_ptr(), gb.data_ptr() + 4 * Cc,
+           1.0 / cnt, 1e-5, None, y.data_ptr(), st.data_ptr(), N, H, W, Cc, H, W, Cc, 3, 1, 1, C.stream_ptr())
+    hh.sync()
+    C.call('hrnet_conv_ring_enable', 1)
+    assert hh.rel_err(hh.from_nhwc(y, Cc), ref) <= TOL
 
 
 BS_CASES = [
@@ -215,3 +250,51 @@ def test_ring_input_gradient_with_backward_statistics(case):
     scale = dz.double().abs().sum((0, 2, 3)).max().item()
     assert float((r1[0] - ref_rows[0]).abs().max()) <= (2 * TOL + 1e-5) * scale
     assert float((r1 - r0).abs().max() / r0.abs().max()) <= (1e-5 if H != 8 else 2e-3)
+
+
+def test_recorded_backward_statistics_launch_keeps_its_kernel_family():
+    """HR_OP_CONV i[17] (hrnet_conv_route): a plan sizes a backward-statistics launch's rows buffer for the kernel family
+    chosen when it was recorded; flipping hrnet_conv_ring_enable() afterwards must not change how many rows the launch
+    writes. Route 2 (ring) with the ring switched off fails loudly, route 1 (tile walk) with the ring on writes the
+    tile-walking body's rows."""
+    hh, C = _h(), _C()
+    from hipnet._capi import HrOp
+    N, H, W, Cc = 8, 16, 16, 128
+    g = torch.Generator().manual_seed(3)
+    dy = _q(torch.randn(N, Cc, H, W, generator=g))
+    w = _q(torch.randn(Cc, Cc, 3, 3, generator=g) / np.sqrt(Cc * 9))
+    bs_y = _q(torch.randn(N, Cc, H, W, generator=g))
+    wp, _, _ = hh.pack_weights(w, DT, mode=1)
+    dyd, byd = hh.nhwc(dy, DT), hh.nhwc(bs_y, DT)
+    C.call('hrnet_conv_ring_enable', 1)
+    assert C.call('hrnet_conv_route', 1, N, H, W, Cc, Cc, 3, 1) == 2
+    rows_ring = C.call('hrnet_conv_rows_bwdstats', 1, N, H, W, Cc, Cc, 3, 1)
+    C.call('hrnet_conv_ring_enable', 0)
+    assert C.call('hrnet_conv_route', 1, N, H, W, Cc, Cc, 3, 1) == 1
+    rows_walk = C.call('hrnet_conv_rows_bwdstats', 1, N, H, W, Cc, Cc, 3, 1)
+    assert rows_ring != rows_walk, 'the case must distinguish the two families'
+
+    def run(route, rows_n):
+        y = torch.zeros(N, H, W, Cc, dtype=DT, device=hh.DEV)
+        rows = torch.full((max(rows_ring, rows_walk) + 1, 2, Cc), float('nan'), dtype=torch.float32, device=hh.DEV)
+        op = HrOp()
+        op.kind = C.OP_CONV
+        for k, val in enumerate((1, N, H, W, Cc, H, W, Cc, 3, 1, 0, 0, 0, 0, 0, 0, 0, route)):
+            op.i[k] = val
+        for k, t in ((0, dyd), (1, wp), (5, y), (6, rows), (7, byd)):
+            op.p[k] = C.ptr(t)
+        C.call('hrnet_program_run', ctypes.byref(op), 1, C.stream_ptr())
+        hh.sync()
+        written = int((~torch.isnan(rows[:, 0, 0])).sum())
+        assert written == rows_n, (route, written, rows_n)
+        return rows[:rows_n].double().sum(0).cpu()
+
+    C.call('hrnet_conv_ring_enable', 1)
+    r_walk = run(1, rows_walk)              # recorded for the tile walk: the ring switch does not pull it over
+    r_ring = run(2, rows_ring)
+    assert float((r_walk - r_ring).abs().max() / r_ring.abs().max()) <= 1e-5
+    C.call('hrnet_conv_ring_enable', 0)
+    with pytest.raises(RuntimeError, match='recorded for the LDS-ring'):
+        run(2, rows_ring)
+    run(1, rows_walk)
+    C.call('hrnet_conv_ring_enable', 1)

@@ -136,6 +136,56 @@ def test_poseaggr_scale_linearity_and_zero_offset():
     assert float(lin.abs().max()) < 1e-4
 
 
+def test_config5_backward_at_full_size():
+    """BASELINE config 5 at its FULL size (B=64, 21 channels, 64x64, deformable groups 21, dilation 12 - the middle
+    dilation of pose_hrnet_PoseAggr.py:508-516), BACKWARD: (a) zero offsets: input / weight / bias gradients equal
+    F.conv2d's autograd (reference test.py:37-69 applied to the gradients); (b) the backward is linear in grad_output
+    for fixed offsets (reference test.py:262-302 checks the same pass for im2col_step invariance); (c) input and
+    offset gradients of images 0-1 of the B=64 launch against the float64 oracle run on those two images (both are
+    per-image quantities), the weight gradient of a two-image launch against the oracle's."""
+    from deformable_conv import DeformConvFunction
+    rng = np.random.default_rng(5)
+    B, Cc, H, dil = 64, 21, 64, 12
+    x = torch.from_numpy(rng.standard_normal((B, Cc, H, H)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((Cc, Cc, 3, 3)) * 0.1).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.random(Cc).astype(np.float32)).to(DEV)
+    go = torch.from_numpy(rng.standard_normal((B, Cc, H, H)).astype(np.float32)).to(DEV)
+    go2 = torch.from_numpy(rng.standard_normal((B, Cc, H, H)).astype(np.float32)).to(DEV)
+
+    def grads(offset, g, xs=x):
+        t = [v.clone().requires_grad_(True) for v in (xs, offset, w, b)]
+        out = DeformConvFunction.apply(t[0], t[1], t[2], t[3], 1, dil, dil, 1, Cc, 64)
+        out.backward(g)
+        return [v.grad for v in t]
+
+    # (a) zero offsets
+    zero = torch.zeros(B, Cc * 18, H, H, device=DEV)
+    gx, _, gw, gb = grads(zero, go)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(xr, wr, br, 1, dil, dil).backward(go)
+    assert float((gx - xr.grad).abs().max()) <= 1e-4 * max(1.0, float(xr.grad.abs().max()))
+    assert float((gw - wr.grad).abs().max()) <= 2e-4 * max(1.0, float(wr.grad.abs().max()))
+    assert float((gb - br.grad).abs().max()) <= 2e-4 * max(1.0, float(br.grad.abs().max()))
+    # (b) linearity in grad_output, offsets of a few pixels
+    off = torch.from_numpy((rng.standard_normal((B, Cc * 18, H, H)) * 3).astype(np.float32)).to(DEV)
+    g1, g2, g12 = grads(off, go), grads(off, go2), grads(off, go + 2 * go2)
+    for name, a1, a2, a12 in zip(('input', 'offset', 'weight', 'bias'), g1, g2, g12):
+        want = a1 + 2 * a2
+        assert float((a12 - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max())), name
+    # (c) the oracle on images 0-1
+    c = dict(input=x[:2].cpu().numpy().astype(np.float64), offset=off[:2].cpu().numpy().astype(np.float64),
+             weight=w.cpu().numpy().astype(np.float64))
+    gi, goff, gw_ref, gb_ref = D.deform_conv_backward(c['input'], c['offset'], c['weight'],
+                                                      go[:2].cpu().numpy().astype(np.float64), (1, 1), (dil, dil),
+                                                      (dil, dil), 1, Cc)
+    for name, got, want in (('input', g1[0][:2], gi), ('offset', g1[1][:2], goff)):
+        sc = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got.cpu().numpy() - want).max() <= 5e-5 * sc, name
+    _, _, gw2, gb2 = grads(off[:2].contiguous(), go[:2].contiguous(), xs=x[:2].contiguous())
+    assert np.abs(gw2.cpu().numpy() - gw_ref).max() <= 5e-5 * max(1.0, float(np.abs(gw_ref).max()))
+    assert np.abs(gb2.cpu().numpy() - gb_ref).max() <= 5e-5 * max(1.0, float(np.abs(gb_ref).max()))
+
+
 def test_bad_arguments_fail_loudly():
     from deformable_conv import DeformConvFunction
     z = torch.zeros

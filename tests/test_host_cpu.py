@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libhrnet_hip.so lacks ' + name
     assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
-    assert _capi.call('hrnet_abi_version') == 1
+    assert _capi.call('hrnet_abi_version') == _capi.ABI_VERSION == 2
 
 
 def test_host_side_shape_helpers_are_pure():
@@ -325,3 +325,38 @@ def test_gradient_exchange_two_ranks_gloo():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2] and len(res[0][2]) >= 2     # same bucket cuts on both ranks
+
+
+def test_flat_adam_moments_are_remapped_by_parameter_name_across_flat_layouts():
+    """FlatAdam checkpoints carry [(name, offset, numel)]: moments written under the module-order flat buffer (round 2)
+    or under another permutation land on the same PARAMETERS after load, and a foreign checkpoint is refused."""
+    from hipnet.optim import legacy_layout, remap_flat
+    order = ['a.weight', 'stage2.0.fuse_layers.0.1.0.weight', 'b.weight', 'stage3.0.branches.2.0.conv1.weight', 'c.bias']
+    size = {'a.weight': 6, 'stage2.0.fuse_layers.0.1.0.weight': 4, 'b.weight': 3,
+            'stage3.0.branches.2.0.conv1.weight': 5, 'c.bias': 2}
+    # current layout: main region in module order, then the late region (fuse layers / wide branches)
+    cur_names = ['a.weight', 'b.weight', 'c.bias', 'stage2.0.fuse_layers.0.1.0.weight', 'stage3.0.branches.2.0.conv1.weight']
+    cur, off = [], 0
+    for n in cur_names:
+        cur.append((n, off, size[n]))
+        off += size[n]
+    total = off
+    old = legacy_layout(cur, order + ['frozen.temp'])
+    assert [n for n, _o, _k in old] == order and old[1] == ('stage2.0.fuse_layers.0.1.0.weight', 6, 4)
+    saved = torch.zeros(total)
+    val = {n: float(i + 1) for i, n in enumerate(order)}
+    for n, o, k in old:
+        saved[o:o + k] = val[n]
+    got = remap_flat(saved, old, cur, total)
+    for n, o, k in cur:
+        assert torch.all(got[o:o + k] == val[n]), n
+    # same layout: the tensor passes through untouched; round trip old -> cur -> old restores the original
+    assert remap_flat(got, cur, cur, total) is got
+    assert torch.equal(remap_flat(got, cur, old, total), saved)
+    # (layouts come back from torch.load as lists of lists)
+    assert torch.equal(remap_flat(saved, [list(t) for t in old], cur, total), got)
+    with pytest.raises(ValueError):
+        remap_flat(saved, old[:-1], cur, total)
+    bad = [(n, o, k + (1 if n == 'b.weight' else 0)) for n, o, k in old]
+    with pytest.raises(ValueError):
+        remap_flat(saved, bad, cur, total)

@@ -768,6 +768,27 @@ def test_final_preds_with_post_process_and_image_space_map():
         assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
 
 
+def test_core_inference_matches_reference_fixture(golden_dir):
+    """SURVEY 8 a14 / a15 pinned: core.inference.get_max_preds / get_final_preds (HIP arg-max kernel behind them)
+    against outputs of the reference's own lib/core/inference.py:18-85 (tests/golden/make_golden_inference.py).
+    Arg-max coordinates and maxima bit-exact (ties, never-positive and all-zero maps, non-square maps); image-space
+    coordinates to 1e-3 of a pixel (the reference applies a float64 3-point affine, the product the closed-form
+    similarity it equals without rotation)."""
+    from config import get_cfg_defaults
+    from core.inference import get_final_preds, get_max_preds
+    g = np.load(os.path.join(golden_dir, 'inference_preds.npz'))
+    for tag in ('sq', 'rect'):
+        preds, maxvals = get_max_preds(g['hm_' + tag])
+        assert np.array_equal(preds, g['preds_' + tag]) and np.array_equal(maxvals, g['maxvals_' + tag])
+        assert preds.dtype == np.float32 and maxvals.shape == g['maxvals_' + tag].shape
+    for pp in (0, 1):
+        cfg = get_cfg_defaults()
+        cfg.TEST.POST_PROCESS = bool(pp)
+        got, gmax = get_final_preds(cfg, g['fp_hm'].copy(), g['fp_center'], g['fp_scale'])
+        assert np.array_equal(gmax, g['fp_maxvals_pp%d' % pp])
+        assert np.abs(got - g['fp_preds_pp%d' % pp]).max() <= 1e-3, np.abs(got - g['fp_preds_pp%d' % pp]).max()
+
+
 def test_spatial_softmax_with_temperature_forward_backward():
     """pose_hrnet_softmax.py:520-524: softmax over each map times a (trainable) temperature"""
     from hipnet import _capi as C

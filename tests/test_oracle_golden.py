@@ -193,3 +193,23 @@ def test_w48_eval_forward_matches_reference_fixture(golden_dir):
         sd['last_layer.1.running_var'] = torch.from_numpy(g['softmax.stat.last_layer.1.running_var'])
         hs, _, _ = O.hrnet_forward(sd, extra, x, training=False, softmax_head=True)
         np.testing.assert_allclose(hs[0, :, 40, 20:44].numpy(), g['softmax.heatmaps_slice'], rtol=1e-3, atol=1e-8)
+
+
+def test_core_inference_oracle_matches_reference_fixture(golden_dir):
+    """the oracle's get_max_preds / final_preds_oracle against outputs of the reference's own
+    lib/core/inference.py functions (tests/golden/make_golden_inference.py; cv2.getAffineTransform is the one
+    call restated there). Integer work: bit-exact; the image-space map: float64 solve vs the reference's
+    float64 matrix applied to float32 coordinates -> 1e-4 of a pixel."""
+    g = np.load(os.path.join(golden_dir, 'inference_preds.npz'))
+    for tag in ('sq', 'rect'):
+        preds, maxvals = O.get_max_preds(g['hm_' + tag])
+        assert np.array_equal(preds, g['preds_' + tag]) and preds.dtype == g['preds_' + tag].dtype
+        assert np.array_equal(maxvals, g['maxvals_' + tag])
+    for pp in (0, 1):
+        want, wmax = g['fp_preds_pp%d' % pp], g['fp_maxvals_pp%d' % pp]
+        got, gmax = O.final_preds_oracle(bool(pp), g['fp_hm'], g['fp_center'], g['fp_scale'])
+        assert np.array_equal(gmax, wmax)
+        assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()
+    # the refinement moved something (the fixture exercises it) and left border / flat peaks alone
+    d = g['fp_preds_pp1'] - g['fp_preds_pp0']
+    assert np.abs(d).max() > 0 and np.all(d[:, :3] == 0) and np.all(d[2, 5] == 0)
