@@ -17,9 +17,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-I', os.path.join(REPO, 'include'), '-I', CSRC, '-Wno-unused-result']
 
 
-# per-file extra flags (none at present). Round 3 compiled conv_ring.hip and head_mix.hip with -fno-slp-vectorize to
-# hide wrong backward-statistics rows; the cause was an LDS store-data hazard in the statistics epilogue, now pinned
-# in source (common.h: hr_pin / hr_lds_stores_done; DESIGN section 4, trap 4).
+# per-file extra flags (none at present). Round 3 compiled conv_ring.hip and head_mix.hip with -fno-slp-vectorize to hide
+# wrong backward-statistics rows; round 4 narrowed the failure to ONE SLP-packed statement (the sum(dz*y) accumulate,
+# `v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,0,1]`), which is now a scalar inline-asm FMA in every epilogue that has it
+# (csrc/common.h hr_fma_acc; DESIGN section 4, trap 4). Taking packed f32 away from EVERY file
+# (`-Xclang -target-feature -Xclang -packed-fp32-ops`) ends the failure as well and costs 0.2 ms/step.
 EXTRA = {}
 
 

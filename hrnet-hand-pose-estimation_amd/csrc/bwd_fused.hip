@@ -31,6 +31,10 @@
 
 #include "common.h"
 
+#ifndef HR_FUSED_XRAW
+#define HR_FUSED_XRAW 1     // (0: measurement builds without the raw-input LDS image, scratch/xraw_variant.sh)
+#endif
+
 namespace {
 
 struct BwdArgs {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   // input (bs_y == x: the second conv of a block, whose input relu(bn1(y1)) is y1 read through its BatchNorm) the
   // epilogue takes y1 at the pixel from this image instead of fetching the tensor a second time: one tensor pass of
   // five less for half of the fused launches, bit-identical statistics. (f32: the images leave no room.)
-  constexpr bool XRAW = ES == 2;
+  constexpr bool XRAW = ES == 2 && HR_FUSED_XRAW != 0;
   constexpr int XRBYTES = XRAW ? ABYTES : 0;
   static_assert(GBYTES + ABYTES + WBYTES + YBYTES + XRBYTES + CBYTES <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) char lds[GBYTES + ABYTES + WBYTES + YBYTES + XRBYTES + CBYTES];
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
         for (int k = 0; k < 8; ++k) {
           const float vv = pok[fp] ? v[k] : 0.f;
           s1[k] += vv;
-          s2[k] = fmaf(vv, yb[k], s2[k]);
+          hr_fma_acc(s2[k], vv, yb[k]);
         }
       }
     }
@@ -679,14 +683,12 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
       s1[k] = wave_sum16(s1[k]);
       s2[k] = wave_sum16(s2[k]);
     }
-    hr_pin(s1); hr_pin(s2);
     if (li == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         sl[(wave * 2 + 0) * CB + lg * 8 + k] = s1[k];
         sl[(wave * 2 + 1) * CB + lg * 8 + k] = s2[k];
       }
-      hr_lds_stores_done();
     }
     __syncthreads();
     if (tid < 2 * CB) {
@@ -778,9 +780,9 @@ struct FusedCfg {
 // Variant: 0 = 16x16 tiles, 8 waves, one workgroup per CU; 1 = 16x16 tiles, 4 waves, two per CU;
 // 2 = 8x16 tiles, 4 waves, two or three per CU. (HRNET_FUSED_VARIANT overrides the default for measurements.)
 inline int fused_variant(int cop) {
-  static const int v = getenv("HRNET_FUSED_VARIANT") ? atoi(getenv("HRNET_FUSED_VARIANT")) : -1;
-  static const int v32 = getenv("HRNET_FUSED_V32") ? atoi(getenv("HRNET_FUSED_V32")) : v;
-  static const int v64 = getenv("HRNET_FUSED_V64") ? atoi(getenv("HRNET_FUSED_V64")) : v;
+  static const int v = hr_knob("HRNET_FUSED_VARIANT", -1);
+  static const int v32 = hr_knob("HRNET_FUSED_V32", v);
+  static const int v64 = hr_knob("HRNET_FUSED_V64", v);
   return cop <= 32 ? v32 : v64;
 }
 
@@ -822,15 +824,15 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   // half the CUs: measured on MI355X inside the training step (4 lanes in flight), 128 workgroups per launch
   // beat 256 by 0.6 ms/step (20.6 vs 21.3 ms; 64: 22.0, 96: 22.0, 160: 20.7) - a grid that takes every CU with a
   // 100 KB / 256-VGPR workgroup locks the other lanes' kernels out - and it halves the slab traffic
-  static const int cus = getenv("HRNET_FUSED_CUS") ? atoi(getenv("HRNET_FUSED_CUS")) : 128;
+  static const int cus = hr_knob("HRNET_FUSED_CUS", 128);
   // ... except where the launch is the whole step for a while: the 64-channel 3x3 conv of a layer1 Bottleneck
   // (64x64 maps: 2048 workgroup-tiles at batch 64) sits in the single-lane tail of the backward pass and takes
   // every CU (165 us on 128 CUs)
-  static const int big = getenv("HRNET_FUSED_CUS_BIG") ? atoi(getenv("HRNET_FUSED_CUS_BIG")) : 256;
-  static const int cus128 = getenv("HRNET_FUSED_CUS_128") ? atoi(getenv("HRNET_FUSED_CUS_128")) : 128;   // (measurement)
+  static const int big = hr_knob("HRNET_FUSED_CUS_BIG", 256);
+  static const int cus128 = hr_knob("HRNET_FUSED_CUS_128", 128);   // (measurement)
   // (measurement: separate grids for the 32- and 64-channel instantiations, which run side by side on two lanes)
-  static const int cus32 = getenv("HRNET_FUSED_CUS32") ? atoi(getenv("HRNET_FUSED_CUS32")) : cus;
-  static const int cus64 = getenv("HRNET_FUSED_CUS64") ? atoi(getenv("HRNET_FUSED_CUS64")) : cus;
+  static const int cus32 = hr_knob("HRNET_FUSED_CUS32", cus);
+  static const int cus64 = hr_knob("HRNET_FUSED_CUS64", cus);
   const int small = c.cop == 32 ? cus32 : cus64;
   int ns = (c.cop == 128 ? cus128 : (long long)tiles * ncb * c.th >= 2048 * 16 ? big : small) * c.per_cu / ncb;
   if (ns < 1) ns = 1;
@@ -908,7 +910,7 @@ static int bwd_fused_launch(int dtype, const void* dz, const void* y, const floa
   a.atomic = atomic; a.Cout_real = Cout_real; a.Cin_real = Cin_real;
 #ifdef HR_MEASURE
   { static const char* sp = getenv("HRNET_FUSED_STAMP_PTR"); a.stamp = sp ? (unsigned long long*)strtoull(sp, nullptr, 16) : nullptr; }
-  { static const int abl = getenv("HRNET_FUSED_ABLATE") ? atoi(getenv("HRNET_FUSED_ABLATE")) : 0; a.ablate = abl; }
+  { static const int abl = hr_knob("HRNET_FUSED_ABLATE", 0); a.ablate = abl; }
 #endif
   const unsigned grid = (unsigned)((a.nsplit + 7) / 8 * 8 * a.ncb);
   hipStream_t s = (hipStream_t)stream;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               s1[j * 8 + k] += v[k];
-              s2[j * 8 + k] = fmaf(v[k], yb[k], s2[j * 8 + k]);
+              hr_fma_acc(s2[j * 8 + k], v[k], yb[k]);
             }
           }
         }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
           if (a.bs_y) {
             v16_unpack<T>(qb[k], yb);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) t2[j] = fmaf(dv[j], yb[j], t2[j]);
+            for (int j = 0; j < VEC; ++j) hr_fma_acc(t2[j], dv[j], yb[j]);
           }
 #pragma unroll
           for (int j = 0; j < VEC; ++j) t1[j] += dv[j];
@@ -312,7 +312,6 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
         s1[k] = wave_sum16(s1[k]);
         s2[k] = wave_sum16(s2[k]);
       }
-      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int j = 0; j < NG; ++j)
@@ -321,7 +320,6 @@ __global__ __launch_bounds__(256, (CI > 64 ? 1 : 2)) void bwd_pw_kernel(PwArgs a
             sl[(wave * 2 + 0) * CI + j * 32 + lg * 8 + k] = s1[j * 8 + k];
             sl[(wave * 2 + 1) * CI + j * 32 + lg * 8 + k] = s2[j * 8 + k];
           }
-        hr_lds_stores_done();
       }
       __syncthreads();
       if (tid < 2 * CI) {
@@ -396,7 +394,7 @@ extern "C" int hrnet_bwd_pw_rows_supported(int dtype, int Cin, int Cout) {
 extern "C" int hrnet_bwd_pw_splits(int dtype, long long pixels, int Cin, int Cout) {
   if (!hrnet_bwd_pw_supported(dtype, Cin, Cout) || pixels <= 0) return 0;
   const long long tiles = (pixels + 63) / 64;
-  static const int wgs = getenv("HRNET_PW_WGS") ? atoi(getenv("HRNET_PW_WGS")) : 256;
+  static const int wgs = hr_knob("HRNET_PW_WGS", 256);
   long long ns = wgs < tiles ? wgs : tiles;
   long long even = ns;
   while (even > 1 && tiles % even != 0) --even;

@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 (CDNA4) HRNet kernels.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,6 +93,16 @@ __device__ __forceinline__ f32x4 mma16<float>(const V16& a, const V16& b, f32x4 
   return c;
 }
 
+// Measurement knobs (grid sizes, kernel variants, instantiation masks ...): honoured only when HRNET_MEASURE=1 is set -
+// the scratch/ sweep scripts set it - so that a stray variable cannot change what a recorded program launches. Product
+// switches are few and live on the host side (HRNET_DETERMINISTIC, HRNET_WGRAD_ATOMIC, HRNET_DP_PLAN, HRNET_LANES).
+inline int hr_knob(const char* name, int dflt) {
+  static const bool on = getenv("HRNET_MEASURE") != nullptr && atoi(getenv("HRNET_MEASURE")) == 1;
+  if (!on) return dflt;
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 __device__ __forceinline__ float wave_sum16(float v) {
   // sum over the 16 lanes that share (lane >> 4)
   v += __shfl_xor(v, 1);
@@ -100,34 +111,16 @@ __device__ __forceinline__ float wave_sum16(float v) {
   v += __shfl_xor(v, 8);
   return v;
 }
-// LDS store-data hazard (compiler trap 4; scratch/lds_war_t.hip): hipcc 7.2 sinks the last
-// `v += shfl_xor(v, 8)` of the sums above into the `if (li == 0)` block that stores them and - with SLP packing the
-// adds into v_pk_add_f32 - interleaves them with the stores, re-using the data registers of a ds_write_b128 issued two
-// instructions earlier for the next pair of sums. The LDS unit fetches a queued store's data quarter-wave by quarter-wave
-// when the instruction reaches the head of its queue (16 ds_bpermute are still ahead of it), the VALU write is not held
-// back, and the hazard recognizer knows the rule for VMEM stores of more than 64 bits only: now and then the last
-// quarter-wave (lanes 48-63) stored the NEXT pair's low word (even channels) - wrong statistics rows, run-to-run
-// different. hr_pin() materialises every value in its own register before the first store is issued;
-// hr_lds_stores_done() keeps the registers from being re-used until the LDS unit has consumed them.
-// (HR_TRAP4: experiment builds of scratch/trap4.sh only - 0 = round 3's code, 1 = the wait behind the stores only,
-// 2 = the register pin only, 3 = a wait in place of the pin; never defined in the shipped library)
-template <int N>
-__device__ __forceinline__ void hr_pin(float (&v)[N]) {
-#if defined(HR_TRAP4) && (HR_TRAP4 == 0 || HR_TRAP4 == 1)
-  (void)v;
-#elif defined(HR_TRAP4) && HR_TRAP4 == 3
-  (void)v;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#pragma unroll
-  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
-#endif
-}
-__device__ __forceinline__ void hr_lds_stores_done() {
-#if defined(HR_TRAP4) && (HR_TRAP4 == 0 || HR_TRAP4 == 2 || HR_TRAP4 == 3)
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+// acc += a * b as ONE scalar v_fma_f32 the vectoriser cannot touch: the sum(dz * y) accumulate of the backward-statistics
+// epilogues. hipcc 7.2's SLP pass turns two neighbouring accumulates into `v_pk_fma_f32 acc2, dz2, y2, acc2
+// op_sel:[0,1,0] op_sel_hi:[1,0,1]` (y2 = a bf16 pair unpacked high half first), and inside conv_ring's input-gradient
+// launches that instruction returned a wrong LOW half in lanes 48-63 in about every second launch (run-to-run
+// different; DESIGN section 4, trap 4: scratch/trap4_run.py reproduces it, the experiment builds of
+// scratch/trap4_build2.sh show that taking THIS statement away from the vectoriser - and nothing else - ends it,
+// scratch/pk_fma_t.hip that the instruction sequence alone does not fail). Every epilogue that accumulates
+// sum(dz * y) goes through here.
+__device__ __forceinline__ void hr_fma_acc(float& acc, float a, float b) {
+  asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 __device__ __forceinline__ float wave_sum64(float v) {

@@ -9,7 +9,7 @@ namespace {
 // workgroup -> pixel-walk mapping of the tile-walking bodies (conv_body.h): contiguous runs per XCD (HRNET_CONV_XCD=0:
 // consecutive walks on consecutive XCDs, as rounds 1-2)
 inline int conv_xcd_runs() {
-  static const int v = getenv("HRNET_CONV_XCD") ? atoi(getenv("HRNET_CONV_XCD")) : 1;
+  static const int v = hr_knob("HRNET_CONV_XCD", 1);
   return v;
 }
 // which specialised body serves a launch (see conv_body.h)

@@ -623,7 +623,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
           for (int k = 0; k < C::LANE_C; ++k) {
             const float dz = (!masked || mv[k] > 0.f) ? vals[k] : 0.f;
             s1[k] += dz;
-            s2[k] = fmaf(dz, yv[k], s2[k]);
+            hr_fma_acc(s2[k], dz, yv[k]);
             if (a.bs_store_masked) vals[k] = dz;     // what is stored IS the next BatchNorm backward's dz
           }
         }
@@ -656,7 +656,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
       s1[k] = wave_sum16(s1[k]);
       s2[k] = wave_sum16(s2[k]);
     }
-    hr_pin(s1); hr_pin(s2);
     if (li == 0) {
 #pragma unroll
       for (int k = 0; k < C::LANE_C; ++k) {
@@ -664,7 +663,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a) {
         sl[(wp * 2 + 0) * BN + cl] = s1[k];
         sl[(wp * 2 + 1) * BN + cl] = s2[k];
       }
-      hr_lds_stores_done();
     }
     __syncthreads();
     if (tid < 2 * BN) {

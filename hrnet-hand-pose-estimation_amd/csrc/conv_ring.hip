@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
             for (int k = 0; k < C::LANE_C; ++k) {
               const float dz = (!masked || mv[k] > 0.f) ? vals[k] : 0.f;
               s1[k] += dz;
-              s2[k] = fmaf(dz, yv[k], s2[k]);
+              hr_fma_acc(s2[k], dz, yv[k]);
               if (a.bs_store_masked) vals[k] = dz;     // what is stored IS the next BatchNorm backward's dz
             }
           }
@@ -538,7 +538,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
       s1[k] = wave_sum16(s1[k]);
       s2[k] = wave_sum16(s2[k]);
     }
-    hr_pin(s1); hr_pin(s2);
     if (li == 0) {
 #pragma unroll
       for (int k = 0; k < C::LANE_C; ++k) {
@@ -546,7 +545,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
         sl[(wpx * 2 + 0) * NB + cl] = s1[k];
         sl[(wpx * 2 + 1) * NB + cl] = s2[k];
       }
-      hr_lds_stores_done();
     }
     lds_barrier();
     if (tid < 2 * NB) {
@@ -590,15 +588,15 @@ static_assert(ring_stage_bytes(HR_RING_MAXC) <= ring_xsb(4) && ring_stage_bytes(
 static_assert(ring_stage_bytes(256) <= ring_xsb(3) && ring_stage_bytes(256) <= ring_xsb(5), "w32's widest branch");
 inline RingPlan ring_plan(int N, int H, int W, int Cin, int Cout, bool bs) {
   // (measurement: HRNET_RING_IDS = bit mask of the instantiations that may be chosen)
-  static const int ids = getenv("HRNET_RING_IDS") ? atoi(getenv("HRNET_RING_IDS")) : 0x7e;
+  static const int ids = hr_knob("HRNET_RING_IDS", 0x7e);
   const RingPlan p = ring_plan_all(N, H, W, Cin, Cout, bs);
   if (!bs && p.id && ring_stage_bytes(Cin) > ring_xsb(p.id)) return RingPlan{0, 0, 0, 0, 0, 0};
   return ((ids >> p.id) & 1) ? p : RingPlan{0, 0, 0, 0, 0, 0};
 }
 inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs) {
   (void)N;
-  static const int wide8 = getenv("HRNET_RING_TI8") ? atoi(getenv("HRNET_RING_TI8")) : 4;   // (measurement: 2 or 4)
-  static const int wide16 = getenv("HRNET_RING_TI16") ? atoi(getenv("HRNET_RING_TI16")) : 1;   // (measurement: 1 or 2)
+  static const int wide8 = hr_knob("HRNET_RING_TI8", 4);   // (measurement: 2 or 4)
+  static const int wide16 = hr_knob("HRNET_RING_TI16", 1);   // (measurement: 1 or 2)
   if (Cin % 32 != 0 || Cout % 16 != 0 || Cin > HR_RING_MAXC) return RingPlan{0, 0, 0, 0, 0, 0};
   if (!bs && Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 1, 32, 2};
   if (!bs && Cin == 64 && Cout >= 32 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 1, 32, 2};
@@ -624,8 +622,8 @@ inline void ring_grid(const RingPlan& p, int N, int H, int W, int Cout, int& til
   tpw = 1;
   if (p.per_cu > 0) {
     // (measurement overrides: workgroups of the two narrow instantiations)
-    static const int wgs1 = getenv("HRNET_RING_WGS1") ? atoi(getenv("HRNET_RING_WGS1")) : 0;
-    static const int wgs2 = getenv("HRNET_RING_WGS2") ? atoi(getenv("HRNET_RING_WGS2")) : 0;
+    static const int wgs1 = hr_knob("HRNET_RING_WGS1", 0);
+    static const int wgs2 = hr_knob("HRNET_RING_WGS2", 0);
     int target = 256 * p.per_cu;
     if (p.id == 1 && wgs1 > 0) target = wgs1;
     if (p.id == 2 && wgs2 > 0) target = wgs2;
@@ -649,8 +647,7 @@ extern "C" int hrnet_conv_ring_enable(int on) {
 
 int hr_conv_ring_enabled() {
   if (g_ring_enabled < 0) {
-    const char* e = getenv("HRNET_CONV_RING");
-    g_ring_enabled = e ? atoi(e) : 1;
+    g_ring_enabled = hr_knob("HRNET_CONV_RING", 1);     // (the run-time switch is hrnet_conv_ring_enable())
   }
   return g_ring_enabled;
 }

@@ -144,14 +144,12 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
         s1[c] = wave_sum16(s1[c]);
         s2[c] = wave_sum16(s2[c]);
       }
-      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           sl[(wp * 2 + 0) * G_BN + n0 + c] = s1[c];
           sl[(wp * 2 + 1) * G_BN + n0 + c] = s2[c];
         }
-        hr_lds_stores_done();
       }
     }
   }
@@ -170,7 +168,7 @@ __global__ __launch_bounds__(G_NT) void gemm_pw_kernel(GemmArgs a) {
 
 // 1 if hr_gemm_pw serves this 1x1 stride-1 conv launch (bf16, the head's 480 -> 480 shape class)
 int hr_gemm_pw_supported(int dtype, int Cin, int Cout) {
-  static const bool off = getenv("HRNET_GEMM_PW") && atoi(getenv("HRNET_GEMM_PW")) == 0;
+  static const bool off = hr_knob("HRNET_GEMM_PW", 1) == 0;
   return !off && dtype == HR_BF16 && Cin % 32 == 0 && Cin >= 256 && Cout >= 256 && Cout <= G_BN && Cout % 8 == 0;
 }
 

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
           const float dz = (!a.inner_relu || z > 0.f) ? v[g][c] : 0.f;
           if constexpr (MODE == 1) {
             s1[c] += dz;
-            s2[c] = fmaf(dz, yf[c], s2[c]);
+            hr_fma_acc(s2[c], dz, yf[c]);
           } else {
             o[c] = fmaf(cA[c], dz, fmaf(cB[c], yf[c], cC[c]));
           }
@@ -340,14 +340,12 @@ __global__ __launch_bounds__(256, 3) void head_mix_tile_kernel(HeadMixArgs a) {
         s1[c] = wave_sum16(s1[c]);
         s2[c] = wave_sum16(s2[c]);
       }
-      hr_pin(s1); hr_pin(s2);
       if (li == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           sl[(wave * 2 + 0) * HM_CH + sb * 32 + lg * 8 + c] = s1[c];
           sl[(wave * 2 + 1) * HM_CH + sb * 32 + lg * 8 + c] = s2[c];
         }
-        hr_lds_stores_done();
       }
     }
   }
@@ -455,7 +453,7 @@ __global__ __launch_bounds__(256) void head_mix_f32_kernel(HeadMixArgs a) {
           const float dz = (!a.inner_relu || z > 0.f) ? v[c] : 0.f;
           if constexpr (MODE == 1) {
             s1[c] += dz;
-            s2[c] = fmaf(dz, yv[c], s2[c]);
+            hr_fma_acc(s2[c], dz, yv[c]);
           } else {
             o[c] = fmaf(a.coef[n0 + c], dz, fmaf(a.coef[a.Cout + n0 + c], yv[c], a.coef[2 * a.Cout + n0 + c]));
           }

@@ -439,7 +439,7 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   // measured on MI355X (scratch/wgrad_micro.py): fastest with ~512 workgroups in total for 3x3 and ~1024
   // for 1x1 tiles, and only when every split walks the same number of tiles (an uneven split costs
   // 20-30 %). Each split costs one f32 slab of Cout*taps*Cin written and re-read by hrnet_wgrad_reduce.
-  static const int wdiv = getenv("HRNET_WGRAD_DIV") ? atoi(getenv("HRNET_WGRAD_DIV")) : 1;   // (measurement override)
+  static const int wdiv = hr_knob("HRNET_WGRAD_DIV", 1);   // (measurement override)
   const int target = (ks == 1 ? 1024 : 512) / wdiv;
   int ns = target / (gy * gz);
   if (ns < 1) ns = 1;

@@ -31,14 +31,28 @@ class AverageMeter(object):
         self.config = config
         self.criterion = criterion
         L = config.LOSS
-        self.total_loss = 0.
-        self.heatmap_loss = 0. if L.WITH_HEATMAP_LOSS else None
-        self.pose2d_loss = 0. if L.WITH_POSE2D_LOSS else None
+        # Running sums stay ON THE DEVICE: the reference adds `loss.item()` three times per step
+        # (lib/core/function.py:1334-1344), i.e. three host syncs that empty the launch queue - +0.9 ms on a 15.5 ms
+        # step here (bench.py --pose2d-loss). The attributes below read the same numbers, syncing only when they are
+        # read (every PRINT_FREQ steps and at the end of an epoch).
+        self._sums = {'total_loss': 0.}
+        if L.WITH_HEATMAP_LOSS:
+            self._sums['heatmap_loss'] = 0.
+        if L.WITH_POSE2D_LOSS:
+            self._sums['pose2d_loss'] = 0.
         self.pose3d_loss = 0. if L.WITH_POSE3D_LOSS else None
         self.time_consistency_loss = 0. if L.WITH_TIME_CONSISTENCY_LOSS else None
         self.bone_loss = 0. if L.WITH_BONE_LOSS else None
         self.jointangle_loss = 0. if L.WITH_JOINTANGLE_LOSS else None
         self.n = 0
+
+    def _read(self, key):
+        v = self._sums.get(key)
+        return None if v is None else (float(v.item()) if hasattr(v, 'item') else float(v))
+
+    total_loss = property(lambda self: self._read('total_loss'))
+    heatmap_loss = property(lambda self: self._read('heatmap_loss'))
+    pose2d_loss = property(lambda self: self._read('pose2d_loss'))
 
     def computeAvgLosses(self):
         n = max(self.n, 1)
@@ -58,18 +72,18 @@ class AverageMeter(object):
         names = self.criterion.keys()
         if 'heatmap_loss' in names:
             l = self.criterion['heatmap_loss'](heatmaps_pred, heatmaps_gt)
-            self.heatmap_loss += l.item()
+            self._sums['heatmap_loss'] = self._sums['heatmap_loss'] + l.detach()
             total = total + self.config.LOSS.HEATMAP_LOSS_FACTOR * l
             out['heatmap_loss'] = l
         if 'pose2d_loss' in names:
             l = self.criterion['pose2d_loss'](pose2d_pred[:, :, 0:2], pose2d_gt[:, :, 0:2], visibility=visibility)
-            self.pose2d_loss += l.item()
+            self._sums['pose2d_loss'] = self._sums['pose2d_loss'] + l.detach()
             total = total + self.config.LOSS.POSE2D_LOSS_FACTOR * l
             out['pose2d_loss'] = l
         for other in ('pose3d_loss', 'bone_loss', 'jointangle_loss'):
             if other in names:
                 raise NotImplementedError('{} belongs to model families outside the HRNet 2-D hot path'.format(other))
-        self.total_loss += total.item()
+        self._sums['total_loss'] = self._sums['total_loss'] + total.detach()
         out['total_loss'] = total
         return out
 

@@ -43,6 +43,26 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+# Environment switches. PRODUCT switches are read whenever a plan is recorded (INTEGRATION.md lists them). Every other
+# HRNET_* variable this file knows is a MEASUREMENT switch - it changes which ops a recorded program holds (fusion on /
+# off, lanes, deferral sizes ...) and exists for A/B runs and for the tests that compare a fused path with its unfused
+# form - and is honoured only together with HRNET_MEASURE=1; without it the defaults below are what runs, and a
+# variable that is set but ignored is reported once.
+PRODUCT_ENV = ('HRNET_DETERMINISTIC', 'HRNET_WGRAD_ATOMIC', 'HRNET_DP_PLAN', 'HRNET_LANES')
+_ignored = set()
+
+
+def _knob(name, default):
+    if name in PRODUCT_ENV or os.environ.get('HRNET_MEASURE', '0') == '1':
+        return os.environ.get(name, default)
+    if name in os.environ and name not in _ignored:
+        _ignored.add(name)
+        import warnings
+        warnings.warn('{}={} is a measurement switch and is ignored without HRNET_MEASURE=1'.format(
+            name, os.environ[name]))
+    return default
+
+
 class Act(object):
     __slots__ = ('name', 'N', 'H', 'W', 'C', 't', 'g', 'ginit', 'bn', 'bn_done', 'nuse', 'bwd_rows', 'gmasked')
 
@@ -113,7 +133,7 @@ class Program(object):
 
     def add(self, kind, ints=(), floats=(), ptrs=(), lane=None):
         if self.before_add is not None:
-            self.before_add()
+            self.before_add(self.lane if lane is None else lane)
         op = C.HrOp()
         op.kind = kind
         for k, v in enumerate(ints):
@@ -229,15 +249,15 @@ class Plan(object):
         self.pending = []         # (program, op_index, slot, kind) scratch pointers to patch
         self.bucket_marks = []    # backward op indices after which a gradient bucket is complete
         self.tape_lanes = []
-        self.nlanes = 4 if os.environ.get('HRNET_LANES', '1') != '0' else 1   # module branches
+        self.nlanes = 4 if _knob('HRNET_LANES', '1') != '0' else 1   # module branches
         # weight-gradient lane (off by default): '2' = only the weight gradients of lane 0 (the high-resolution
         # branch, whose HBM-bound elementwise passes make it the critical chain) move to their own lane; '1' =
         # all of them. Measured on MI355X: '2' shortens the dependency-only critical path of the backward
         # program from 14.4 to 12.3 ms but the step stays at 24.4 ms - the step is throughput-bound, not
         # dependency-bound - and '1' is slower.
-        wl = os.environ.get('HRNET_WLANE', '0')
+        wl = _knob('HRNET_WLANE', '0')
         self.wlane = 4 if (self.nlanes > 1 and wl in ('1', '2')) else 0
-        self.defer_lanes = int(os.environ.get('HRNET_DEFER_LANES', '3'))      # side lanes the deferred weight gradients use
+        self.defer_lanes = int(_knob('HRNET_DEFER_LANES', '3'))      # side lanes the deferred weight gradients use
         self.wlane_all = wl == '1'
         self.streams = None
         self.gen = 0              # bumped by every forward run: a backward must see the generation it recorded
@@ -280,7 +300,7 @@ class Plan(object):
         bias = crec.mod.bias
         sums_in = self.bn_sums and xin.bn is not None       # the input's BatchNorm from its batch sums, on the fly
         m_in = xin.bn.mod if xin.bn is not None else None
-        ps = self._pending_sum
+        ps = self._pending_sum.get(self.fwd.lane)
         # (the wide layers' fat LDS-ring launches take one input tensor: their residual sums stay separate launches)
         fat = (ks == 3 and stride == 1 and cin >= 96 and (self.bn_sums or not want_stats)
                and C.call('hrnet_conv_ring_supported', self.dtid, x.N, x.H, x.W, cin, crec.Cout_pad) >= 3)
@@ -288,7 +308,7 @@ class Plan(object):
                 and bias is None and ps['lane'] == self.fwd.lane and not fat):
             # the residual sum that produced x has not been emitted: this conv forms it in its prologue and writes
             # it out on the side (hrnet_conv2d_sum) - one launch and one tensor read less per block
-            self._pending_sum = None
+            del self._pending_sum[self.fwd.lane]
             bt, it = ps['bn_term'], ps['id_term']
             sm = self.bn_sums
             mb = bt.bn.mod
@@ -383,24 +403,25 @@ class Plan(object):
             ptrs += [C.ptr(t.bn.shift) if t.bn else None for t in terms] + [None] * (4 - len(terms))
             emit(C.OP_SUM_TERMS, ints=ints, ptrs=ptrs)
         if hold:
-            self._flush_pending_sum()
-            self._pending_sum = dict(out=out, lane=self.fwd.lane, op=held[0], bn_term=bn_terms[0],
-                                     id_term=next(t for t in terms if t.bn is None))
+            self._flush_pending_sum(self.fwd.lane)
+            self._pending_sum[self.fwd.lane] = dict(out=out, lane=self.fwd.lane, op=held[0], bn_term=bn_terms[0],
+                                                    id_term=next(t for t in terms if t.bn is None))
         for t in terms:
             t.act.nuse += 1
         self._tape(('sum', list(terms), list(shifts), relu_out, out))
         return Val(out)
 
-    def _flush_pending_sum(self):
-        """emit the held-back residual sum as its own launch (its consumer was not a fusable conv)"""
-        ps = self._pending_sum
-        if ps is not None:
-            self._pending_sum = None
-            a, k = ps['op']
-            keep = self.fwd.lane
-            self.fwd.lane = ps['lane']
-            self.fwd.add(*a, **k)
-            self.fwd.lane = keep
+    def _flush_pending_sum(self, lane=None):
+        """emit the held-back residual sum of `lane` (None: of every lane) as its own launch (its consumer was not a
+        fusable conv). One slot per lane: the lanes of a module may be recorded interleaved."""
+        for l in ([lane] if lane is not None else sorted(self._pending_sum)):
+            ps = self._pending_sum.pop(l, None)
+            if ps is not None:
+                a, k = ps['op']
+                keep = self.fwd.lane
+                self.fwd.lane = ps['lane']
+                self.fwd.add(*a, **k)
+                self.fwd.lane = keep
 
     def bilinear_cat(self, vals, name, align=False):
         a0 = vals[0].act
@@ -483,8 +504,8 @@ class Plan(object):
         # residual sums fused into the conv that reads them (hrnet_conv2d_sum): HRNET_FUSE_SUM=0 turns it off.
         # Training only: 18.75 vs 18.92 ms/step; an eval pass is faster with the separate sum kernels (5.25 vs
         # 5.36 ms: the two-tensor prologue re-reads two halos and lengthens the latency-bound conv launches)
-        self.fuse_sums = self.training and os.environ.get('HRNET_FUSE_SUM', '1') != '0'
-        self._pending_sum = None
+        self.fuse_sums = self.training and _knob('HRNET_FUSE_SUM', '1') != '0'
+        self._pending_sum = {}        # lane -> held-back residual sum
         self.n_fused_sums = 0
         self.n_batched_fwd_sums = 0
         self.fwd.before_add = self._flush_pending_sum
@@ -498,7 +519,7 @@ class Plan(object):
         # 480 / 720), 384 in hrnet_sum_terms (SUM_MAXC: the widest BatchNorm that reaches a sum is a branch width -
         # the head's BatchNorm is read by a conv); wider nets fall back to per-BatchNorm finalize launches
         sum_w = max([b.C for n, b in self.bns.items() if not n.startswith('last_layer')] or [0])
-        self.bn_sums = (self.training and contiguous and os.environ.get('HRNET_DETERMINISTIC', '0') != '1'
+        self.bn_sums = (self.training and contiguous and _knob('HRNET_DETERMINISTIC', '0') != '1'
                         and max(b.C for b in self.bns.values()) <= 768 and sum_w <= 384)
         self.bn_finalize_list = []
         if self.bn_sums:
@@ -565,7 +586,7 @@ class Plan(object):
         self.n_head_mix = 0
         self._head_y = None
         self._head_bwd = None
-        mix = (os.environ.get('HRNET_HEAD_MIX', '1') != '0' and not getattr(net.module, 'inter_from_cat', False)
+        mix = (_knob('HRNET_HEAD_MIX', '1') != '0' and not getattr(net.module, 'inter_from_cat', False)
                and 2 <= len(ys) <= 4 and all(v.bn is None and not v.relu for v in ys)
                and sum(v.act.C for v in ys) == c0.Cin and c0.Cin_pad == c0.Cin and c0.Cout_pad == c0.Cout
                and C.call('hrnet_head_mix_supported', self.dtid, ys[0].act.C, c0.Cout_pad) == 1)
@@ -624,17 +645,22 @@ class Plan(object):
         if side:
             self.fwd.fork(side)
             self._tape(('fork', side))
-        for i in range(nb):
+        # recording order of the branches: lane by lane (every block of branch 0, then branch 1 ...), or - HRNET_INTERLEAVE=1,
+        # measurement - block by block across the branches, so that the host hands every lane its first launches at once
+        # (the programs are enqueued in recording order at ~3.5 us per op)
+        interleave = _knob('HRNET_INTERLEAVE', '0') == '1' and len(side) > 0
+        order = ([(i, k) for k in range(max(num_blocks[:nb])) for i in range(nb) if k < num_blocks[i]] if interleave
+                 else [(i, k) for i in range(nb) for k in range(num_blocks[i])])
+        for i, k in order:
             self.fwd.lane = i if i in side else 0
-            for k in range(num_blocks[i]):
-                b = '{}.branches.{}.{}'.format(pre, i, k)
-                a = self.conv(xs[i], cv[b + '.conv1'], 1, bn[b + '.bn1'], relu=True)
-                c = self.conv(a, cv[b + '.conv2'], 1, bn[b + '.bn2'], relu=False)
-                xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
+            b = '{}.branches.{}.{}'.format(pre, i, k)
+            a = self.conv(xs[i], cv[b + '.conv1'], 1, bn[b + '.bn1'], relu=True)
+            c = self.conv(a, cv[b + '.conv2'], 1, bn[b + '.bn2'], relu=False)
+            xs[i] = self.sum([c, xs[i]], [0, 0], True, b + '.out')
         # fuse-layer convolutions stay on the lane of the branch they READ (source-major): they start as
         # soon as that branch is done, and in the backward pass every accumulation into a branch
         # output's gradient is ordered on one lane. The sums wait for all lanes.
-        fuse_lanes = os.environ.get('HRNET_FUSE_LANES', '1') != '0'
+        fuse_lanes = _knob('HRNET_FUSE_LANES', '1') != '0'
         if side and not fuse_lanes:
             self.fwd.lane = 0
             self.fwd.join(side)
@@ -662,11 +688,11 @@ class Plan(object):
         # the sums of the module outputs run on the lane of their output branch (a second fork/join): in the
         # backward pass that spreads a module's 16 sum-term passes over the lanes, and every consumer of a
         # branch gradient sits on that branch's lane
-        sum_lanes = side and fuse_lanes and os.environ.get('HRNET_SUM_LANES', '1') != '0'
+        sum_lanes = side and fuse_lanes and _knob('HRNET_SUM_LANES', '1') != '0'
         # ... or, forward (HRNET_BATCH_SUMFWD, default on): the nb sums as ONE table-driven launch on lane 0 - they are
         # 10-30 us each, and the fork / join around them cost more than running them side by side saved. The tape
         # keeps the ('fork' / 'join', side, 'sums') markers: the backward pass batches its side of them the same way.
-        batch = [] if (sum_lanes and os.environ.get('HRNET_BATCH_SUMFWD', '1') != '0') else None
+        batch = [] if (sum_lanes and _knob('HRNET_BATCH_SUMFWD', '1') != '0') else None
         if sum_lanes:
             if batch is None:
                 self.fwd.fork(side)
@@ -719,7 +745,7 @@ class Plan(object):
         # y.g, and the apply pass reads it from there instead of pooling and masking the full-resolution tensors
         # again (an up-sampled fuse term of branch 0 re-read 2 x 16.8 MB per term). HRNET_KEEP_DZ=0: both passes pool.
         keep_dz = None
-        if y.bwd_rows is None and g_src != C.ptr(y.g) and os.environ.get('HRNET_KEEP_DZ', '1') != '0':
+        if y.bwd_rows is None and g_src != C.ptr(y.g) and _knob('HRNET_KEEP_DZ', '1') != '0':
             keep_dz = C.ptr(y.g)
         if pooled is not None:
             # the reduction ran as one level of a HR_OP_POOL_REDUCE job (its dz is in y.g, its partial rows in `pooled`)
@@ -823,11 +849,11 @@ class Plan(object):
         # written and read back per step before), no reduce launches, and nothing left to do when the last
         # weight-gradient launch ends. HRNET_DETERMINISTIC=1 (or HRNET_WGRAD_ATOMIC=0) keeps slabs + ordered sums
         # (HRNET_WGRAD_ATOMIC=1 beside HRNET_DETERMINISTIC=1: ordered batch statistics, atomic weight gradients - tests).
-        det = os.environ.get('HRNET_DETERMINISTIC', '0') == '1'
-        self.wgrad_atomic = (os.environ.get('HRNET_BATCH_WRED', '1') != '0'
-                             and os.environ.get('HRNET_WGRAD_ATOMIC', '0' if det else '1') != '0')
+        det = _knob('HRNET_DETERMINISTIC', '0') == '1'
+        self.wgrad_atomic = (_knob('HRNET_BATCH_WRED', '1') != '0'
+                             and _knob('HRNET_WGRAD_ATOMIC', '0' if det else '1') != '0')
         # batched backward of the fuse sums (HR_OP_EW_TABLE; HRNET_BATCH_SUMBWD=0: one launch per pass and lane)
-        self.batch_sums = os.environ.get('HRNET_BATCH_SUMBWD', '1') != '0'
+        self.batch_sums = _knob('HRNET_BATCH_SUMBWD', '1') != '0'
         self._batch = None
         self.n_batched_jobs = 0
         relu_of = {}   # act -> relu flag its consumers apply (uniform per act in this network)
@@ -855,12 +881,12 @@ class Plan(object):
                 use_lanes.setdefault(id(a), set()).add(ln)
         # weight-gradient slab sums are batched: every layer keeps its own slab region and ONE table-driven
         # launch per lane segment (or per ~16 MB of gradient on lane 0) sums them
-        self.batch_wred = os.environ.get('HRNET_BATCH_WRED', '1') != '0'
+        self.batch_wred = _knob('HRNET_BATCH_WRED', '1') != '0'
         self._wred = {}            # lane -> pending (slabs tensor, HrWredEnt fields)
         self._wred_tables = []     # (op index, [entries]) patched with the device table at the end
         self._wred_bytes = 0
         self.slab_bytes = 0
-        fuse_stats = self.training and os.environ.get('HRNET_FUSE_BWDSTATS', '1') != '0'
+        fuse_stats = self.training and _knob('HRNET_FUSE_BWDSTATS', '1') != '0'
         self.n_fused_bwdstats = 0
         self._bnrefs = []
         self.n_inline_bnbwd = 0
@@ -879,23 +905,24 @@ class Plan(object):
         # offloaded from lane 0. HRNET_DP_PLAN=1 records that form in a single process (bench.py: what the step of
         # a data-parallel rank costs on one GPU).
         dp = (torch.distributed.is_available() and torch.distributed.is_initialized()
-              and torch.distributed.get_world_size() > 1) or os.environ.get('HRNET_DP_PLAN', '0') == '1'
+              and torch.distributed.get_world_size() > 1) or _knob('HRNET_DP_PLAN', '0') == '1'
         self.dp_plan = dp
         self.defer_wgrad = (self.nlanes > 1 and self.batch_wred and not self.wlane
-                            and os.environ.get('HRNET_DEFER_WGRAD', '1') != '0')
-        self.defer_branch_wgrads = os.environ.get('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
+                            and _knob('HRNET_DEFER_WGRAD', '1') != '0')
+        self.defer_branch_wgrads = _knob('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
         # how much weight-gradient work the single-lane tail can hide: the tail is a stream over the stem / layer1
         # maps, so its length goes with their pixel count; 3.2 MFLOP per tail pixel is what w32 at B=64 hides in full
         # (773 GFLOP behind a 4 ms tail). w48 has 1.9x the work per tail pixel: half of it stays in the modules
         # (deferring all of it: 43.8 ms/step, none: 37.0)
         tail_pixels = self.N * (self.H // 4) * (self.W // 4)
-        self._defer_budget = float(os.environ.get('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
+        self._defer_budget = float(_knob('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
         self._defer_flops = 0.0
-        self.offload_wgrad = self.defer_wgrad and not dp and os.environ.get('HRNET_OFFLOAD_WGRAD', '1') != '0'
+        self.offload_wgrad = self.defer_wgrad and not dp and _knob('HRNET_OFFLOAD_WGRAD', '1') != '0'
         self._offload_rr = 0
         self._offload_lanes = set()
         self._deferred = []
         self._deferred_lanes = []
+        self.late_cuts = []        # (backward op index, flat lo, flat hi, lane): late-region groups final on that lane there
         self.n_deferred_wgrads = 0
         first_fork = next((i for i, e in enumerate(self.tape) if e[0] == 'fork'), None)
         fused_at, fused_skip = self._find_fused_blocks(), set()
@@ -987,7 +1014,7 @@ class Plan(object):
                 if (ups and [q[0] for q in ups] == list(range(1, len(ups) + 1)) and len(ups) <= 3
                         and out.H % (1 << len(ups)) == 0 and out.W % (1 << len(ups)) == 0
                         and 256 // (out.C // (4 if self.dt == torch.float32 else 8)) >= 4 ** (len(ups) - 1)
-                        and os.environ.get('HRNET_POOL_REDUCE', '1') != '0' and os.environ.get('HRNET_KEEP_DZ', '1') != '0'):
+                        and _knob('HRNET_POOL_REDUCE', '1') != '0' and _knob('HRNET_KEEP_DZ', '1') != '0'):
                     L = len(ups)
                     pblocks = C.call('hrnet_ew_table_blocks', C.OP_POOL_REDUCE, self.dtid, out.N, out.H >> 1, out.W >> 1, out.C)
                     ptrs = [C.ptr(out.g), mask]
@@ -1048,7 +1075,7 @@ class Plan(object):
                     # parallelism of many splits, and every split is a slab written and read back - but it must
                     # keep ~100 workgroups (the wide w48 layers have few splits to begin with: dividing those
                     # cost 6 ms per step). measured (w32 B=64, ms/step): divisor 1: 19.97, 2: 19.56, 4: 19.49, 8: 19.97
-                    div = int(os.environ.get('HRNET_DEFER_SPLIT_DIV', '4'))
+                    div = int(_knob('HRNET_DEFER_SPLIT_DIV', '4'))
                     tiles = C.call('hrnet_wgrad_tiles', self.dtid, x.N, y.H, y.W, y.C, x.C, ks, stride)
                     per = C.call('hrnet_wgrad_blocks_per_split', self.dtid, y.H, y.W, y.C, x.C, ks, stride)
                     floor_ = min(nsplit, -(-96 // max(per, 1)))
@@ -1064,7 +1091,8 @@ class Plan(object):
                 if direct:
                     wptrs[4] = C.ptr(net.grad_of(w))
                     if deferred:
-                        self._deferred.append((wints, wptrs, None, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
+                        self._deferred.append((wints, wptrs, None, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks,
+                                               net.offsets[id(w)][0]))
                     elif self.offload_wgrad and lane == 0 and not in_region:
                         l = 1 + self._offload_rr % max(1, self.nlanes - 1)
                         self._offload_rr += 1
@@ -1084,7 +1112,8 @@ class Plan(object):
                                accumulate=1)
                     if deferred:
                         # x.t, y.g and the BatchNorm coefficients of xin stay untouched until the program ends
-                        self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks))
+                        self._deferred.append((wints, wptrs, ent, 2.0 * x.N * y.H * y.W * y.C * x.C * ks * ks,
+                                               net.offsets[id(w)][0]))
                     elif self.offload_wgrad and lane == 0 and not in_region:
                         # a single-lane part of the pass (head, transition1, stem): its weight gradients are off the
                         # dependency chain - they go to a side lane, which idles there (the head) or carries the
@@ -1112,7 +1141,7 @@ class Plan(object):
                         self.bwd.ops[i].i[3] = crec.ks   # real taps of the flattened stem kernel
                 self.bwd.lane = lane
                 if (x is self._head_y and x.g is not None and xin.bn is not None and self.training and ks == 1
-                        and crec.mod.weight.shape[0] <= y.C and os.environ.get('HRNET_HEAD_BWD', '1') != '0'
+                        and crec.mod.weight.shape[0] <= y.C and _knob('HRNET_HEAD_BWD', '1') != '0'
                         and C.call('hrnet_head_mix_supported', self.dtid, y.C, x.C) == 1):
                     # the layer behind the head's BatchNorm (last_layer.3): its input gradient dz = W^T dY is a K = 32
                     # product per pixel - formed here only to gather the BatchNorm-backward sums, and formed AGAIN by
@@ -1155,7 +1184,7 @@ class Plan(object):
                         target.bwd_rows = (rows, nrows)
                         self.n_fused_bwdstats += 1
                         if (target is not x and ptrs[8] is not None and id(x) in self._fused_out_ids
-                                and os.environ.get('HRNET_BS_STORE_MASKED', '1') != '0'):
+                                and _knob('HRNET_BS_STORE_MASKED', '1') != '0'):
                             # x closes a block whose backward is a fused launch: this (last) contribution stores the
                             # gradient already multiplied by x's ReLU mask - no separate mask pass over the tensor
                             store_masked = 1
@@ -1270,12 +1299,12 @@ class Plan(object):
         """tape indices of the 'sum' entries that close a BasicBlock (or an identity Bottleneck) all of whose convs
         the fused kernels serve -> 'basic' / 'bottleneck'"""
         out = {}
-        if not self.training or os.environ.get('HRNET_FUSED_BWD', '1') == '0':
+        if not self.training or _knob('HRNET_FUSED_BWD', '1') == '0':
             return out
         T, L = self.tape, self.tape_lanes
         # (the 128-channel instantiation exists and is tested, but inside the step it loses: 19.32 vs 18.82 ms - its four
         # input-channel blocks re-stage the same 128-channel g tile and a third 128-CU grid queues behind the other two)
-        maxc = int(os.environ.get('HRNET_FUSED_MAXC', '64'))     # (tests: restrict the fused path to narrow layers)
+        maxc = int(_knob('HRNET_FUSED_MAXC', '64'))     # (tests: restrict the fused path to narrow layers)
         for ti in range(2, len(T)):
             e = T[ti]
             if e[0] != 'sum' or T[ti - 1][0] != 'conv' or T[ti - 2][0] != 'conv':
@@ -1303,7 +1332,7 @@ class Plan(object):
                 out[ti] = 'basic'
         # Bottleneck with an identity residual (pose_hrnet.py:60-105; layer1 blocks 1..3): conv1 1x1, conv2 3x3,
         # conv3 1x1, + x, ReLU - the pointwise convs through hrnet_conv1x1_bwd_fused
-        if os.environ.get('HRNET_FUSED_PW', '1') != '0':
+        if _knob('HRNET_FUSED_PW', '1') != '0':
             for ti in range(3, len(T)):
                 e = T[ti]
                 if e[0] != 'sum' or any(T[ti - k][0] != 'conv' for k in (1, 2, 3)):
@@ -1397,7 +1426,7 @@ class Plan(object):
         ref = None
         lim = 16384 if ks == 3 else 8192
         if (y.bwd_rows is not None and y.bwd_rows[1] * y.C <= lim
-                and os.environ.get('HRNET_BNBWD_INLINE', '1') != '0'):
+                and _knob('HRNET_BNBWD_INLINE', '1') != '0'):
             b, m = y.bn, y.bn.mod
             ref = C.HrBnBwdRef()
             ref.rows, ref.gamma = C.ptr(y.bwd_rows[0]), C.ptr(m.weight)
@@ -1551,13 +1580,47 @@ class Plan(object):
         keep = self.bwd.lane
         self.bwd.lane = 0
         self.bwd.fork(side)
-        load = {l: 0.0 for l in side}
-        for wints, wptrs, ent, cost in sorted(self._deferred, key=lambda d: -d[3]):
-            l = min(side, key=lambda q: load[q])
-            load[l] += cost
-            self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
-            if ent is not None:
-                self._wred.setdefault(l, []).append(ent)
+
+        def emit(entries):
+            load = {l: 0.0 for l in side}
+            for wints, wptrs, ent, cost, _off in sorted(entries, key=lambda d: -d[3]):
+                l = min(side, key=lambda q: load[q])
+                load[l] += cost
+                self.bwd.add(C.OP_WGRAD, ints=wints, ptrs=wptrs, lane=l)
+                if ent is not None:
+                    self._wred.setdefault(l, []).append(ent)
+        if self.dp_plan and _knob('HRNET_LATE_GROUPS', '1') != '0':
+            # Data parallelism: the late region of the flat gradient (net._flatten: module by module) leaves in GROUPS of
+            # ~16 MB while the tail runs, instead of in one piece when the program ends. Group by group (highest
+            # offsets first: the modules the backward pass finished first): the group's deferred launches spread over
+            # the side lanes, (slab mode: their ordered sums,) then the other side lanes are joined into the first one,
+            # so that "everything enqueued on side[0] so far" covers the group - and every late gradient that was NOT
+            # deferred, which the fork above put in front. hipnet.optim.GradSync issues the group's all-reduce from
+            # that stream at the recorded op index (late_cuts): the exchange of group g travels while the launches of
+            # group g + 1 run, and nothing of the late region is left when the program ends.
+            net = self.net
+            lo_all, hi_all = int(net.late_start), int(net.trainable_count)
+            starts = sorted({off for (off, n) in (net.offsets[id(p)] for p in net.params if net.is_late(p))})
+            target = int(_knob('HRNET_LATE_GROUP_MB', '16')) << 18            # floats per group
+            bounds = [hi_all]
+            for off in reversed(starts):
+                if bounds[-1] - off >= target:
+                    bounds.append(off)
+            if bounds[-1] != lo_all:
+                if len(bounds) > 1 and bounds[-1] - lo_all < target // 2:
+                    bounds[-1] = lo_all               # a small remainder joins the last group
+                else:
+                    bounds.append(lo_all)
+            for hi_g, lo_g in zip(bounds, bounds[1:]):
+                emit([d for d in self._deferred if lo_g <= d[4] < hi_g])
+                for l in side:
+                    self._flush_wred(l)
+                for l in side[1:]:
+                    self.bwd.sync(l, side[0])
+                self.late_cuts.append((len(self.bwd), lo_g, hi_g, side[0]))
+            self.bwd.lane = 0
+        else:
+            emit(self._deferred)
         self._deferred_lanes = side
         self.n_deferred_wgrads = len(self._deferred)
         self._deferred = []

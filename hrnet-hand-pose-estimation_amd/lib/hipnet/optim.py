@@ -147,7 +147,7 @@ class GradSync(object):
     def _prepare(self, plan):
         net = plan.net
         total = net.total_params
-        self.cuts, self._ranges, self._late = [], {}, None
+        self.cuts, self._ranges, self._late, self._late_ranges = [], {}, None, {}
         deferred = getattr(plan, 'defer_wgrad', False) or getattr(plan, 'offload_wgrad', False)
         # recorded for data parallelism (engine.Plan.dp_plan): only gradients of the flat buffer's late region finish
         # out of order (deferred weight-gradient launches), nothing is offloaded from lane 0
@@ -165,25 +165,45 @@ class GradSync(object):
         else:
             marks = plan.bucket_marks
             if deferred:
-                hi = int(net.late_start)          # the main region in buckets at the marks, the late region at the end
-                self._late = (hi, total)
+                hi = int(net.late_start)          # the main region in buckets at the marks ...
+                groups = list(getattr(plan, 'late_cuts', []) or [])
+                covered = sorted((lo, hi_) for _i, lo, hi_, _l in groups)
+                whole = (bool(covered) and covered[0][0] == hi and covered[-1][1] == int(net.trainable_count)
+                         and all(a[1] == b[0] for a, b in zip(covered, covered[1:])))
+                if whole:
+                    # ... and the late region group by group while the single-lane tail of the pass runs
+                    # (engine.Plan._emit_deferred_wgrads): each group from the side lane it is final on
+                    for op_index, lo, hi_, lane in groups:
+                        self._late_ranges[int(op_index)] = (int(lo), int(hi_), int(lane))
+                    if total > int(net.trainable_count):
+                        self._late = (int(net.trainable_count), total)      # (frozen parameters: zeros, one small range)
+                else:
+                    self._late = (hi, total)      # ... the late region in one piece when the program ends
         top = hi
         last = hi
+        fallback = False
         # (with a late region the main region is a sixth of the gradient - 17 MB for w32: smaller buckets keep its
         # exchange overlapped with the backward pass instead of leaving it to the end with the late region)
-        bucket_bytes = min(self.bucket_bytes, 4 << 20) if self._late is not None else self.bucket_bytes
+        bucket_bytes = min(self.bucket_bytes, 4 << 20) if (self._late is not None or self._late_ranges) else self.bucket_bytes
         for op_index, prefix in marks:
             w = net.convs[prefix].mod.weight
             off = net.offsets[id(w)][0]
             if off > last:        # not monotone: fall back to one exchange at the end
                 self.cuts, self._ranges = [], {}
                 hi = top
+                fallback = True
                 break
             last = off
             if (hi - off) * 4 >= bucket_bytes:
                 self.cuts.append(op_index)
                 self._ranges[op_index] = (off, hi)
                 hi = off
+        if self._late_ranges:
+            if fallback:
+                self._late_ranges = {}            # (non-monotone marks: everything in one exchange at the end)
+                self._late = (hi, total)
+            else:
+                self.cuts = sorted(set(self.cuts) | set(self._late_ranges))
         self._tail = (0, hi)
         self._end = len(plan.bwd)
         self._plan = plan
@@ -194,6 +214,8 @@ class GradSync(object):
             return None
         rows = [{'after_op': int(i), 'offset': int(lo), 'floats': int(hi - lo), 'mb': round((hi - lo) * 4 / 1e6, 2)}
                 for i, (lo, hi) in sorted(self._ranges.items())]
+        rows += [{'after_op': int(i), 'offset': int(lo), 'floats': int(hi - lo), 'mb': round((hi - lo) * 4 / 1e6, 2),
+                  'late_group': True, 'lane': int(lane)} for i, (lo, hi, lane) in sorted(self._late_ranges.items())]
         rows.append({'after_op': int(self._end), 'offset': int(self._tail[0]),
                      'floats': int(self._tail[1] - self._tail[0]),
                      'mb': round((self._tail[1] - self._tail[0]) * 4 / 1e6, 2)})
@@ -201,8 +223,9 @@ class GradSync(object):
             rows.append({'after_op': int(self._end), 'offset': int(self._late[0]),
                          'floats': int(self._late[1] - self._late[0]),
                          'mb': round((self._late[1] - self._late[0]) * 4 / 1e6, 2), 'late_region': True})
+        exposed = sum(r['mb'] for r in rows if r['after_op'] == int(self._end))
         return {'payload': 'f32', 'bucket_bytes_min': int(self.bucket_bytes), 'backward_ops': int(self._end),
-                'buckets': rows}
+                'exposed_mb_after_backward': round(exposed, 2), 'buckets': rows}
 
     def begin(self, plan):
         if self._plan is not plan:
@@ -212,6 +235,20 @@ class GradSync(object):
 
     def after(self, op_index):
         net = self._plan.net
+        late = self._late_ranges.get(op_index)
+        if late is not None and ('late', op_index) not in self._done:
+            # a group of the late region: final on side lane `lane` at this point of the program (the other side lanes
+            # were joined into it), so the collective is issued with THAT stream current - it waits for the group's
+            # launches, not for lane 0's tail
+            self._done.add(('late', op_index))
+            lo, hi, lane = late
+            streams = getattr(self._plan, 'streams', None)
+            st = streams[lane] if streams is not None and lane < len(streams) and streams[lane] is not None else None
+            if st is not None:
+                with torch.cuda.stream(st):
+                    self._works.append(self.dist.all_reduce(net.flat_g[lo:hi], group=self.pg, async_op=True))
+            else:
+                self._works.append(self.dist.all_reduce(net.flat_g[lo:hi], group=self.pg, async_op=True))
         rng = self._ranges.get(op_index)
         if rng is None and op_index == self._end:
             rng = self._tail
@@ -233,9 +270,8 @@ class GradSync(object):
         """wait for the exchanges of this step; any bucket whose mark the backward run did not pass (it was
         executed in pieces around an external gradient) is exchanged now, so no range stays rank-local"""
         if self._plan is not None:
-            for op_index in list(self._ranges) + [self._end]:
-                if op_index not in self._done:
-                    self.after(op_index)
+            for op_index in sorted(set(self._ranges) | set(self._late_ranges)) + [self._end]:
+                self.after(op_index)              # (idempotent: ranges already exchanged are skipped)
         for w in self._works:
             w.wait()
         self._works = []

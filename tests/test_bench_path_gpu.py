@@ -409,6 +409,7 @@ def test_bf16_op_by_op_with_exact_inputs_against_fp32_device_path(fused, monkeyp
     # ... and the LDS-ring convolutions are bf16 only: the wide layers they serve keep their residual sums as separate
     # launches, so one run records both dtypes without fused sums (ring kernels op by op), the other without the ring
     # (hrnet_conv2d_sum op by op)
+    monkeypatch.setenv('HRNET_MEASURE', '1')       # (measurement switches are ignored without it)
     if fused == 'unfused':
         monkeypatch.setenv('HRNET_FUSED_BWD', '0')
         ring_prev = C.call('hrnet_conv_ring_enable', 0)      # (the library reads HRNET_CONV_RING once: use the switch)
@@ -548,6 +549,7 @@ def test_fused_backward_matches_unfused_backward(dtype, monkeypatch):
     from hipnet import synth
     batch = synth.rhd_batch(4, seed=31, img_h=128, img_w=128)
     monkeypatch.setenv('HRNET_DETERMINISTIC', '1')     # bit-reproducible batch statistics: the two forward passes agree exactly
+    monkeypatch.setenv('HRNET_MEASURE', '1')           # (measurement switches are ignored without it)
     monkeypatch.setenv('HRNET_FUSED_BWD', '0')
     mu, sd = _model(dtype, init='reference', salt=6)
     hm_u, _, loss_u, gu = _hip_step(mu, batch)

@@ -178,9 +178,17 @@ def test_config5_backward_at_full_size():
     gi, goff, gw_ref, gb_ref = D.deform_conv_backward(c['input'], c['offset'], c['weight'],
                                                       go[:2].cpu().numpy().astype(np.float64), (1, 1), (dil, dil),
                                                       (dil, dil), 1, Cc)
-    for name, got, want in (('input', g1[0][:2], gi), ('offset', g1[1][:2], goff)):
-        sc = max(1.0, float(np.abs(want).max()))
-        assert np.abs(got.cpu().numpy() - want).max() <= 5e-5 * sc, name
+    # the offset gradient is the derivative of a bilinear sample: discontinuous where the sample position crosses a
+    # pixel centre (or the -1 / H border rule, deform_im2col_cuda.cuh:173) - a position within f32 rounding of an integer
+    # may fall on the other side in the float64 oracle (a handful of the 3 M elements at this size): those are left out
+    h, w_ = D._sample_positions(c['offset'], (2, H, H), 3, 3, (1, 1), (dil, dil), (dil, dil), Cc)
+    near = (np.abs(h - np.round(h)) < 2e-4) | (np.abs(w_ - np.round(w_)) < 2e-4)          # [B, DG, K, Ho, Wo]
+    keep = ~np.repeat(near[:, :, :, None], 2, axis=3).reshape(2, Cc * 18, H, H)
+    assert keep.mean() > 0.999
+    got_in = g1[0][:2].cpu().numpy()
+    assert np.abs(got_in - gi).max() <= 5e-5 * max(1.0, float(np.abs(gi).max())), 'input'
+    got_off = g1[1][:2].cpu().numpy()
+    assert np.abs((got_off - goff) * keep).max() <= 5e-5 * max(1.0, float(np.abs(goff).max())), 'offset'
     _, _, gw2, gb2 = grads(off[:2].contiguous(), go[:2].contiguous(), xs=x[:2].contiguous())
     assert np.abs(gw2.cpu().numpy() - gw_ref).max() <= 5e-5 * max(1.0, float(np.abs(gw_ref).max()))
     assert np.abs(gb2.cpu().numpy() - gb_ref).max() <= 5e-5 * max(1.0, float(np.abs(gb_ref).max()))

@@ -85,10 +85,18 @@ def _worker(rank, world, port, q, atomic='0'):
         # weight-gradient launches are deferred to the single-lane tail only in the flat buffer's late region, which
         # leaves in its own exchange when the pass ends
         plan = sync._plan
-        late = [b for b in sync.describe()['buckets'] if b.get('late_region')]
+        d = sync.describe()
+        late = [b for b in d['buckets'] if b.get('late_region')]
+        groups = sorted((b for b in d['buckets'] if b.get('late_group')), key=lambda b: b['offset'])
         same = same and plan.wgrad_atomic == (atomic == '1') and plan.dp_plan and plan.defer_wgrad and not plan.offload_wgrad and plan.n_deferred_wgrads > 20
-        same = same and len(late) == 1 and late[0]['offset'] == net.late_start and late[0]['floats'] > 10_000_000
-        q.put((rank, same, len(sync.cuts), errs))
+        # the late region leaves in groups while the single-lane tail runs (engine.Plan.late_cuts): >= 6 exchanges issued
+        # at cuts BEFORE the program's last op, tiling [late_start, trainable_count), nothing of it left for the end
+        same = same and not late and len(groups) >= 6 and groups[0]['offset'] == net.late_start
+        same = same and groups[-1]['offset'] + groups[-1]['floats'] == net.trainable_count
+        same = same and all(a['offset'] + a['floats'] == b['offset'] for a, b in zip(groups, groups[1:]))
+        same = same and all(g['after_op'] < d['backward_ops'] for g in groups) and d['exposed_mb_after_backward'] <= 30.0
+        same = same and sum(g['floats'] for g in groups) > 10_000_000
+        q.put((rank, same, len(sync.cuts), errs + [len(groups), d['exposed_mb_after_backward']]))
         dist.destroy_process_group()
     except Exception as e:   # surface the failure in the parent
         import traceback

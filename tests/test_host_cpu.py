@@ -307,6 +307,42 @@ def _gradsync_worker(rank, world, port, q):
         sync.after(c)
     sync.finish()
     ok = ok and bool(torch.all(net.flat_g == total / world))
+    # (6) ... and with the late region in GROUPS (engine.Plan.late_cuts: op index, flat range, side lane): every group
+    # leaves at its own cut, before the program's last op, and nothing of it is left for the end
+    net.flat_g.fill_(float(rank + 1))
+    net.trainable_count = 6000
+    plan4 = FakePlan()
+    plan4.net, plan4.bwd, plan4.defer_wgrad, plan4.dp_plan = net, plan.bwd, True, True
+    plan4.bucket_marks = plan3.bucket_marks
+    plan4.late_cuts = [(33, 5500, 6000, 1), (35, 5000, 5500, 1), (37, 4000, 5000, 1)]
+    sync.begin(plan4)
+    d = sync.describe()
+    groups = [b for b in d['buckets'] if b.get('late_group')]
+    ok = ok and len(groups) == 3 and not [b for b in d['buckets'] if b.get('late_region')]
+    ok = ok and d['exposed_mb_after_backward'] <= 4000 * 4 / 1e6 and sync.cuts == sorted(sync.cuts)
+    spans = sorted((b['offset'], b['offset'] + b['floats']) for b in d['buckets'])
+    ok = ok and spans[0][0] == 0 and spans[-1][1] == 6000 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    issued_before_end = 0
+    for c in [c for c in sync.cuts if c < len(plan4.bwd)]:
+        n0 = len(sync._works)
+        sync.after(c)
+        issued_before_end += len(sync._works) - n0
+    for w_ in sync._works:
+        w_.wait()
+    ok = ok and issued_before_end >= 3 + 1 and bool(torch.all(net.flat_g[4000:] == total))    # the late region is done
+    sync.after(len(plan4.bwd))
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
+    # groups that do not tile the late region are ignored (one piece at the end, as in (5))
+    plan4.late_cuts = [(33, 5500, 6000, 1)]
+    sync._plan = None
+    net.flat_g.fill_(float(rank + 1))
+    sync.begin(plan4)
+    ok = ok and not sync._late_ranges and [b for b in sync.describe()['buckets'] if b.get('late_region')][0]['offset'] == 4000
+    for c in sync.cuts + [len(plan4.bwd)]:
+        sync.after(c)
+    sync.finish()
+    ok = ok and bool(torch.all(net.flat_g == total / world))
     q.put((rank, ok, cuts))
     dist.destroy_process_group()
 

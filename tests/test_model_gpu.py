@@ -303,6 +303,7 @@ def test_residual_sums_fused_into_the_next_conv_change_nothing(monkeypatch):
     x, gt = torch.from_numpy(b['imgs']).cuda(), torch.from_numpy(b['heatmaps']).cuda()
     res = {}
     for mode in ('1', '0'):
+        monkeypatch.setenv('HRNET_MEASURE', '1')       # (measurement switches are ignored without it)
         monkeypatch.setenv('HRNET_FUSE_SUM', mode)
         model, _, _ = make_model('bf16', 7)
         model.train()

@@ -129,6 +129,7 @@ def _step(monkeypatch, env):
     from hipnet import synth
     from core.loss import HeatmapLoss
     import test_bench_path_gpu as T
+    monkeypatch.setenv('HRNET_MEASURE', '1')       # (HRNET_BATCH_SUM* are measurement switches: ignored without it)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     m, _ = T._model('bf16', init='reference', salt=3)
