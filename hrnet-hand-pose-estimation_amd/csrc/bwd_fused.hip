@@ -32,7 +32,7 @@
 #include "common.h"
 
 #ifndef HR_FUSED_XRAW
-#define HR_FUSED_XRAW 1     // (0: measurement builds without the raw-input LDS image, scratch/xraw_variant.sh)
+#define HR_FUSED_XRAW 0     // 1: keep x as stored in a second LDS image and take the statistics operand from it when bs_y == x (measured: -17 MB per launch, +0.05 ms/step - the extra 20 KB of LDS cost more than the bytes)
 #endif
 
 namespace {
@@ -145,7 +145,15 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   // (tap, ci-fragment) lists were uneven - 3 / 2 per wave - and their `if (fr < NFR)` tests cut the phase into 24
   // read -> wait -> 2 MFMA blocks per tile).
   constexpr int NBLK = FCO * (CB / 16);
-  constexpr int KSPLIT = NBLK >= NW ? 1 : NW / NBLK;
+  // (round 4, measured and rejected: TWO co-fragments per wave - 2 + 9 transposed fragment reads for 18 MFMAs per
+  // k-step instead of 1 + 9 for 9, the pixel axis split over twice as many wave groups. In-kernel stamps had the phase
+  // at 1955 cycles per 16x16 tile for 1150 cycles of MFMA issue, so it looked bound by the LDS pipe; with the change
+  // the 32-channel instantiation went from 43.0 to 41.2 us alone, the 64-channel one from 35.7 to 42.2 (256 VGPRs and
+  // 60 bytes of scratch) and the step from 15.45 to 16.15 ms: what bounds the phase is the latency of a dependent
+  // transposing read at two waves per SIMD, and registers are what pays for hiding it. TWO = true brings it back.)
+  constexpr int KS2 = NBLK >= NW * 2 ? 1 : NW * 2 / NBLK;         // k-groups when a wave takes two blocks
+  constexpr bool TWO = false && ES == 2 && FCO % 2 == 0 && NBLK * KS2 >= NW * 2 && (BM / KSTEP) % KS2 == 0;
+  constexpr int KSPLIT = TWO ? KS2 : (NBLK >= NW ? 1 : NW / NBLK);
   constexpr int NWB = NW / KSPLIT;             // waves of one k-group
   constexpr int BPW = NBLK / NWB;              // blocks per wave (consecutive co-fragments of one ci-fragment)
   constexpr int NFR = 9 * (CB / 16);           // (tap, ci-fragment) outputs per co-fragment = 18
@@ -703,26 +711,28 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   FSTAMP();
   // ---- the k-groups' partial weight gradients meet in LDS, in a fixed order: group 0 keeps the total ----
   if constexpr (KSPLIT > 1) {
-    static_assert((KSPLIT - 1) * NWB * BPW * 9 * 1024 <= GBYTES + ABYTES + WBYTES, "k-group exchange fits the LDS images");
-    __syncthreads();          // (the statistics reduction above read its scratch in the same bytes)
-    f32x4* kl = (f32x4*)lds;  // [KSPLIT - 1][NWB][BPW * 9][64 lanes]
-    if (kh > 0) {
+    // one group per round (a round's exchange is NWB * BPW * 9 KB: all groups at once would not fit beside nothing)
+    static_assert(NWB * BPW * 9 * 1024 <= GBYTES + ABYTES + WBYTES, "one k-group's exchange fits the LDS images");
+    f32x4* kl = (f32x4*)lds;  // [NWB][BPW * 9][64 lanes]
 #pragma unroll
-      for (int q = 0; q < BPW; ++q)
+    for (int g = 1; g < KSPLIT; ++g) {
+      __syncthreads();        // (the statistics reduction / the previous round read the same bytes)
+      if (kh == g) {
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) kl[((((kh - 1) * NWB + wb) * BPW + q) * 9 + tp) * 64 + lane] = accw[q][tp];
-    }
-    __syncthreads();
-    if (kh == 0) {
+        for (int q = 0; q < BPW; ++q)
 #pragma unroll
-      for (int g = 1; g < KSPLIT; ++g)
+          for (int tp = 0; tp < 9; ++tp) kl[((wb * BPW + q) * 9 + tp) * 64 + lane] = accw[q][tp];
+      }
+      __syncthreads();
+      if (kh == 0) {
 #pragma unroll
         for (int q = 0; q < BPW; ++q)
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) {
-            const f32x4 o = kl[((((g - 1) * NWB + wb) * BPW + q) * 9 + tp) * 64 + lane];
+            const f32x4 o = kl[((wb * BPW + q) * 9 + tp) * 64 + lane];
             accw[q][tp] = f32x4{accw[q][tp].x + o.x, accw[q][tp].y + o.y, accw[q][tp].z + o.z, accw[q][tp].w + o.w};
           }
+      }
     }
   }
   const bool wwriter = kh == 0;

@@ -11,6 +11,13 @@
 // (wave-uniform broadcast reads). NCHW f32 like the reference op.
 #include "common.h"
 
+#ifndef DCN_LDS_TAPS
+#define DCN_LDS_TAPS 9    // taps of dcn_bwd_fused_kernel whose scattered input gradient goes through LDS atomics (the others: global atomics)
+#endif
+#ifndef DCN_ABLATE
+#define DCN_ABLATE 0      // measurement builds (scratch/dcn_ablate.sh): 1 no LDS atomics, 2 one weight vector per tap, 4 no offset-gradient stores
+#endif
+
 namespace {
 
 struct DcnArgs {
@@ -349,9 +356,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   }
   const int plane_o = a.Ho * a.Wo;
   const size_t obase0 = ((size_t)b * a.DG + c) * 2 * KK * plane_o;
-  const int po = threadIdx.x / KK, pk = threadIdx.x % KK;      // this thread's (o, k) pair in phase 2
-  const bool pair = threadIdx.x < a.Og * KK;
-  float dw = 0.f;
+  float* gout_plane = a.gin + ((size_t)b * a.C + c) * HW;       // (zeroed by the host when DCN_LDS_TAPS < 9)
+  // phase 2 on the matrix pipe (round 4): dW[o][k] = sum_p g[o][p] * sample[k][p] is a (32 x 16) x K = 256 product per
+  // step. v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate): lane (i = lane & 15, kk = lane >> 4) of a
+  // 16-pixel chunk reads FOUR consecutive pixels 4 kk .. 4 kk + 3 of its row with one ds_read_b128 and feeds them to
+  // four MFMAs (the pairing of pixels with k indices is free as long as both operands use the same one). A wave takes
+  // every fourth chunk: 4 chunks x (2 + 1) 16-byte reads per step instead of 128 per (o, k) thread - the LDS pipe was
+  // active 87 % of the kernel's time before (SQ_LDS_IDX_ACTIVE 2.0 M cycles per CU of 2.3 M), phase 2 alone issued
+  // ~3000 of its ~6300 LDS cycles per step. Rows beyond Og / taps beyond 9 are fed zeros.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = lane & 15, mk = lane >> 4;
+  f32x4 accw[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // o tiles 0-15, 16-31 x taps (cols)
   for (int p0 = 0; p0 < plane_o; p0 += 256) {
     const int p = p0 + threadIdx.x;
     const bool live = p < plane_o;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
         float gc = 0.f;
         const float4* wk = reinterpret_cast<const float4*>(wl + k * OGP);
 #pragma unroll
-        for (int o = 0; o < OGP / 4; ++o) {
+        for (int o = 0; o < ((DCN_ABLATE & 2) ? 1 : OGP / 4); ++o) {
           const float4 w4 = wk[o];
           gc = fmaf(w4.x, g[4 * o], gc);
           gc = fmaf(w4.y, g[4 * o + 1], gc);
@@ -396,13 +411,23 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
           val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
           gh = gc * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
           gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
-          if (ok1) atomicAdd(gpl + hl * a.W + wl_, gc * hh * hw);
-          if (ok2) atomicAdd(gpl + hl * a.W + wh, gc * hh * lw);
-          if (ok3) atomicAdd(gpl + hh_ * a.W + wl_, gc * lh * hw);
-          if (ok4) atomicAdd(gpl + hh_ * a.W + wh, gc * lh * lw);
+#if !(DCN_ABLATE & 1)
+          // the scattered input gradient: float atomics, taps < DCN_LDS_TAPS into the LDS plane (ds_add_f32: measured
+          // ~128 cycles per wave instruction = two cycles per lane, 0.74 of this kernel's 1.06 ms when all nine taps
+          // go there), the others straight into the global plane (global_atomic_add_f32, memory-side: another pipe)
+          float* gdst = k < DCN_LDS_TAPS ? gpl : gout_plane;
+          if (ok1) atomicAdd(gdst + hl * a.W + wl_, gc * hh * hw);
+          if (ok2) atomicAdd(gdst + hl * a.W + wh, gc * hh * lw);
+          if (ok3) atomicAdd(gdst + hh_ * a.W + wl_, gc * lh * hw);
+          if (ok4) atomicAdd(gdst + hh_ * a.W + wh, gc * lh * lw);
+#endif
         }
+#if !(DCN_ABLATE & 4)
         a.goff[obase0 + (size_t)(2 * k) * plane_o + p] = gh;
         a.goff[obase0 + (size_t)(2 * k + 1) * plane_o + p] = gw;
+#else
+        if (gh == 12345.f) a.goff[obase0 + p] = gw;
+#endif
         vl[k * LD + threadIdx.x] = val;
       }
     } else {
@@ -412,24 +437,55 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
       for (int k = 0; k < KK; ++k) vl[k * LD + threadIdx.x] = 0.f;
     }
     __syncthreads();
-    if (pair) {
-      const float4* gr = reinterpret_cast<const float4*>(gl + po * LD);
-      const float4* vr = reinterpret_cast<const float4*>(vl + pk * LD);
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < 64; q += 2) {
-        const float4 g0 = gr[q], v0 = vr[q], g1 = gr[q + 1], v1 = vr[q + 1];
-        s0 = fmaf(g0.x, v0.x, s0); s0 = fmaf(g0.y, v0.y, s0); s0 = fmaf(g0.z, v0.z, s0); s0 = fmaf(g0.w, v0.w, s0);
-        s1 = fmaf(g1.x, v1.x, s1); s1 = fmaf(g1.y, v1.y, s1); s1 = fmaf(g1.z, v1.z, s1); s1 = fmaf(g1.w, v1.w, s1);
+    {
+      const bool r0 = mi < OGP, r1 = 16 + mi < OGP, kc = mi < KK;
+      const float* g0p = gl + (r0 ? mi : 0) * LD + 4 * mk;
+      const float* g1p = gl + (r1 ? 16 + mi : 0) * LD + 4 * mk;
+      const float* vp = vl + (kc ? mi : 0) * LD + 4 * mk;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = (wave + 4 * q) * 16;                  // this wave's q-th chunk of 16 pixels
+        const float4 a0 = r0 ? *reinterpret_cast<const float4*>(g0p + ch) : z4;
+        const float4 a1 = r1 ? *reinterpret_cast<const float4*>(g1p + ch) : z4;
+        const float4 bv = kc ? *reinterpret_cast<const float4*>(vp + ch) : z4;
+        accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, accw[0], 0, 0, 0);
+        accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, accw[0], 0, 0, 0);
+        accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, accw[0], 0, 0, 0);
+        accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, accw[0], 0, 0, 0);
+        if constexpr (OGP > 16) {
+          accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, accw[1], 0, 0, 0);
+          accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, accw[1], 0, 0, 0);
+          accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, accw[1], 0, 0, 0);
+          accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, accw[1], 0, 0, 0);
+        }
       }
-      dw += s0 + s1;
     }
   }
   __syncthreads();
   float* out = a.gin + ((size_t)b * a.C + c) * HW;
-  for (int i = threadIdx.x; i < HW; i += 256) out[i] = gpl[i];
+  if constexpr (DCN_LDS_TAPS >= KK) {
+    for (int i = threadIdx.x; i < HW; i += 256) out[i] = gpl[i];
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) atomicAdd(out + i, gpl[i]);      // beside the taps added in place
+  }
+  // the four waves' partial products meet in LDS (fixed order: deterministic); D layout: col (lane & 15) = tap,
+  // row 4 * (lane >> 4) + r = output channel of the tile
+  float* red = gl;                   // [4 waves][32 o][16 taps] (the step buffers are free: 8 KB of gl's >= 24 KB)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float v4[4] = {accw[t].x, accw[t].y, accw[t].z, accw[t].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 32 + t * 16 + 4 * mk + r) * 16 + mi] = v4[r];
+  }
+  __syncthreads();
   // partial[b][o][c][k]: one [Og][C][K] block per image
-  if (pair) a.partial[(size_t)b * a.Og * a.C * KK + ((size_t)po * a.C + c) * KK + pk] = dw;
+  if ((int)threadIdx.x < a.Og * KK) {
+    const int po = threadIdx.x / KK, pk = threadIdx.x % KK;
+    const float dw = ((red[(0 * 32 + po) * 16 + pk] + red[(1 * 32 + po) * 16 + pk]) + red[(2 * 32 + po) * 16 + pk]) +
+                     red[(3 * 32 + po) * 16 + pk];
+    a.partial[(size_t)b * a.Og * a.C * KK + ((size_t)po * a.C + c) * KK + pk] = dw;
+  }
 }
 
 // one wave per weight element: lanes stride over the per-block partials, fixed-shape tree at the end
@@ -545,6 +601,7 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
   if (groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 80 * 1024 && B <= 65535 &&
       hrnet_deform_conv_wgrad_blocks(B, Ho, Wo) >= B) {
     a.c0 = 0; a.Cg = Cg; a.o0 = 0; a.Og = Og;
+    if (DCN_LDS_TAPS < 9) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
     if (ogp == 24) {
       want_lds(dcn_bwd_fused_kernel<24, 9>, lds_one);
       hipLaunchKernelGGL((dcn_bwd_fused_kernel<24, 9>), dim3(C, B), dim3(256), lds_one, s, a);
