@@ -30,6 +30,10 @@ struct DcnArgs {
   float* gin;         // [B,C,H,W]   (atomic accumulation: zeroed by the caller)
   float* goff;        // [B,DG*2*K,Ho,Wo]
   float* partial;     // [blocks][Og][Cg][K]
+  // modulated form (DCNv2, reference src/cuda/modulated_deform_im2col_cuda.cuh:128-257): every sample is multiplied by
+  // mask[b, dg*K + k, y, x]; NULL = plain v1
+  const float* mask;  // [B,DG*K,Ho,Wo] or NULL
+  float* gmask;       // [B,DG*K,Ho,Wo] gradient of the mask (backward, with mask)
   int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, DG;
   int c0, Cg, o0, Og;  // this launch's conv group: input channels [c0,c0+Cg), outputs [o0,o0+Og)
 };
@@ -88,6 +92,11 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int oc0, int oc
 #pragma unroll
       for (int u = 0; u < 3; ++u)
         vv[u] = (k0 + u < K && dcn_inside(hh[u], ww[u], a.H, a.W)) ? dcn_sample(plane, a.H, a.W, hh[u], ww[u]) : 0.f;
+      if (a.mask) {
+        const float* mp = a.mask + ((size_t)b * a.DG + c / cpd) * K * plane_o + (size_t)y * a.Wo + x;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) vv[u] *= mp[(size_t)(k0 + u < K ? k0 + u : K - 1) * plane_o];
+      }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int k = k0 + u < K ? k0 + u : K - 1;
@@ -152,7 +161,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnArgs a) {
         gc = fmaf(w4.z, g[4 * o + 2], gc);
         gc = fmaf(w4.w, g[4 * o + 3], gc);
       }
-      float gh = 0.f, gw = 0.f;
+      float gh = 0.f, gw = 0.f, gm = 0.f;
+      // modulated: column = mask * sample, so d/d sample carries the mask and d/d mask = gc * sample
+      // (modulated_deform_im2col_cuda.cuh:196-257, 259-330)
+      const size_t mbase = ((size_t)b * a.DG + dgi) * K * plane_o + (size_t)y * a.Wo + x + (size_t)k * plane_o;
+      const float gcu = gc;
+      if (a.mask) gc *= a.mask[mbase];
       if (dcn_inside(h, w, a.H, a.W)) {
         const int hl = (int)floorf(h), wl_ = (int)floorf(w);
         const int hh_ = hl + 1, wh = wl_ + 1;
@@ -164,6 +178,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnArgs a) {
         // d sample / d h, d w (deform_im2col_cuda.cuh:82-124)
         gh = gc * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
         gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
+        gm = gcu * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
         if (ok1) atomicAdd(gplane + hl * a.W + wl_, gc * hh * hw);
         if (ok2) atomicAdd(gplane + hl * a.W + wh, gc * hh * lw);
         if (ok3) atomicAdd(gplane + hh_ * a.W + wl_, gc * lh * hw);
@@ -175,6 +190,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnArgs a) {
       const bool first = c % cpd == 0;
       gp[0] = first ? gh : gp[0] + gh;
       gp[plane_o] = first ? gw : gp[plane_o] + gw;
+      if (a.gmask) a.gmask[mbase] = first ? gm : a.gmask[mbase] + gm;
     }
   }
 }
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnArgs a) {
           const float h = (float)(y * a.sh - a.ph + i * a.dh) + a.off[obase + (size_t)(2 * k) * plane_o];
           const float w = (float)(x * a.sw - a.pw + j * a.dw) + a.off[obase + (size_t)(2 * k + 1) * plane_o];
           if (dcn_inside(h, w, a.H, a.W)) val = dcn_sample(plane, a.H, a.W, h, w);
+          if (a.mask) val *= a.mask[((size_t)b * a.DG + c / cpd) * K * plane_o + (size_t)k * plane_o + (size_t)y * a.Wo + x];
         }
         vl[k * LD + threadIdx.x] = val;
       }
@@ -539,16 +556,16 @@ int fill_common(DcnArgs& a, int B, int C, int H, int W, int Co, int kh, int kw, 
 
 }  // namespace
 
-extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset, const float* weight,
-                                         const float* bias, float* output, int B, int C, int H, int W, int Co,
-                                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                                         int groups, int deformable_groups, hr_stream_t stream) {
+static int dcn_forward_impl(const float* input, const float* offset, const float* mask, const float* weight,
+                            const float* bias, float* output, int B, int C, int H, int W, int Co,
+                            int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                            int groups, int deformable_groups, hr_stream_t stream) {
   DcnArgs a = {};
   int Ho, Wo;
   if (int e = fill_common(a, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, &Ho, &Wo))
     return e;
   HR_REQUIRE(input && offset && weight && output, "deform_conv_forward: null pointer");
-  a.in = input; a.off = offset; a.w = weight; a.bias = bias; a.out = output;
+  a.in = input; a.off = offset; a.w = weight; a.bias = bias; a.out = output; a.mask = mask;
   const int Cg = C / groups, Og = Co / groups, K = kh * kw;
   HR_REQUIRE((size_t)OC * Cg * K * 4 <= 96 * 1024, "deform_conv_forward: C/groups * kh * kw = %d too large", Cg * K);
   const long long npix = (long long)B * Ho * Wo;
@@ -565,9 +582,35 @@ extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset
   return hr_check_launch("deform_conv_forward");
 }
 
+extern "C" int hrnet_deform_conv_forward(const float* input, const float* offset, const float* weight,
+                                         const float* bias, float* output, int B, int C, int H, int W, int Co,
+                                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                         int groups, int deformable_groups, hr_stream_t stream) {
+  return dcn_forward_impl(input, offset, nullptr, weight, bias, output, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw,
+                          groups, deformable_groups, stream);
+}
+
+// modulated form (DCNv2): mask [B, deformable_groups * kh * kw, Ho, Wo] multiplies every sample
+// (reference lib/deformable_conv/src/modulated_deform_conv.h:10-44, src/cuda/modulated_deform_conv_cuda.cu:20-118)
+extern "C" int hrnet_modulated_deform_conv_forward(const float* input, const float* offset, const float* mask,
+                                                   const float* weight, const float* bias, float* output, int B,
+                                                   int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                                                   int ph, int pw, int dh, int dw, int groups,
+                                                   int deformable_groups, hr_stream_t stream) {
+  HR_REQUIRE(mask, "modulated_deform_conv_forward: null mask");
+  return dcn_forward_impl(input, offset, mask, weight, bias, output, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw,
+                          groups, deformable_groups, stream);
+}
+
 extern "C" int hrnet_deform_conv_wgrad_blocks(int B, int Ho, int Wo) {
   return (int)(((long long)B * Ho * Wo + 256 * WCH - 1) / (256 * WCH));
 }
+
+static int dcn_backward_impl(const float* input, const float* offset, const float* mask, const float* weight,
+                             const float* grad_output, float* grad_input, float* grad_offset, float* grad_mask,
+                             float* grad_weight, float* grad_bias, float* scratch, int B, int C,
+                             int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int groups, int deformable_groups, hr_stream_t stream);
 
 extern "C" int hrnet_deform_conv_backward(const float* input, const float* offset, const float* weight,
                                           const float* grad_output, float* grad_input, float* grad_offset,
@@ -575,6 +618,31 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
                                           int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                                           int dh, int dw, int groups, int deformable_groups,
                                           hr_stream_t stream) {
+  return dcn_backward_impl(input, offset, nullptr, weight, grad_output, grad_input, grad_offset, nullptr, grad_weight,
+                           grad_bias, scratch, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                           deformable_groups, stream);
+}
+
+// gradients of the modulated form: + grad_mask [B, deformable_groups * kh * kw, Ho, Wo]
+// (reference src/cuda/modulated_deform_conv_cuda.cu:120-285)
+extern "C" int hrnet_modulated_deform_conv_backward(const float* input, const float* offset, const float* mask,
+                                                    const float* weight, const float* grad_output,
+                                                    float* grad_input, float* grad_offset, float* grad_mask,
+                                                    float* grad_weight, float* grad_bias, float* scratch, int B,
+                                                    int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                                                    int ph, int pw, int dh, int dw, int groups,
+                                                    int deformable_groups, hr_stream_t stream) {
+  HR_REQUIRE(mask && grad_mask, "modulated_deform_conv_backward: null mask / grad_mask");
+  return dcn_backward_impl(input, offset, mask, weight, grad_output, grad_input, grad_offset, grad_mask, grad_weight,
+                           grad_bias, scratch, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                           deformable_groups, stream);
+}
+
+static int dcn_backward_impl(const float* input, const float* offset, const float* mask, const float* weight,
+                             const float* grad_output, float* grad_input, float* grad_offset, float* grad_mask,
+                             float* grad_weight, float* grad_bias, float* scratch, int B, int C,
+                             int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int groups, int deformable_groups, hr_stream_t stream) {
   DcnArgs a = {};
   int Ho, Wo;
   if (int e = fill_common(a, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, deformable_groups, &Ho, &Wo))
@@ -583,7 +651,7 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
              "deform_conv_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   a.in = input; a.off = offset; a.w = weight; a.gout = grad_output; a.gin = grad_input; a.goff = grad_offset;
-  a.partial = scratch;
+  a.partial = scratch; a.mask = mask; a.gmask = grad_mask;
   const int Cg = C / groups, Og = Co / groups, K = kh * kw;
   HR_REQUIRE(Og <= 64, "deform_conv_backward: out_channels/groups = %d > 64 not supported", Og);
   HR_REQUIRE((size_t)(Og <= 32 ? 32 : 64) * Cg * K * 4 <= 96 * 1024,
@@ -598,7 +666,7 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
   const int ogp = Og <= 24 ? 24 : 32;
   const size_t lds_one = ((size_t)2 * H * W + (size_t)9 * ogp + (size_t)(ogp + 9) * 260) * 4;
   // (scratch holds hrnet_deform_conv_wgrad_blocks() partials of [Og][C][K]; this path writes B of them)
-  if (groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 80 * 1024 && B <= 65535 &&
+  if (!mask && groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 80 * 1024 && B <= 65535 &&
       hrnet_deform_conv_wgrad_blocks(B, Ho, Wo) >= B) {
     a.c0 = 0; a.Cg = Cg; a.o0 = 0; a.Og = Og;
     if (DCN_LDS_TAPS < 9) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
@@ -618,7 +686,7 @@ extern "C" int hrnet_deform_conv_backward(const float* input, const float* offse
     return hr_check_launch("deform_conv_backward");
   }
   const size_t lds_fast = ((size_t)cpd * K * (Og <= 32 ? 32 : 64) + (size_t)cpd * H * W) * 4;
-  const bool fast = Cg % cpd == 0 && lds_fast <= 64 * 1024;
+  const bool fast = !mask && Cg % cpd == 0 && lds_fast <= 64 * 1024;     // (the modulated form runs the generic kernels)
   if (!fast) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
   if (Og <= 32) want_lds(dcn_bwd_data_kernel<32>, (size_t)32 * Cg * K * 4);
   else want_lds(dcn_bwd_data_kernel<64>, (size_t)64 * Cg * K * 4);

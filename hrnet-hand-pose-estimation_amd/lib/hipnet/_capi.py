@@ -148,6 +148,8 @@ _SIGS = {
     'hrnet_deform_conv_forward': [_c_vp] * 5 + [_c_int] * 15 + [_c_vp],
     'hrnet_deform_conv_wgrad_blocks': [_c_int] * 3,
     'hrnet_deform_conv_backward': [_c_vp] * 9 + [_c_int] * 15 + [_c_vp],
+    'hrnet_modulated_deform_conv_forward': [_c_vp] * 6 + [_c_int] * 15 + [_c_vp],
+    'hrnet_modulated_deform_conv_backward': [_c_vp] * 11 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
 _PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_route', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
@@ -167,6 +169,10 @@ def lib():
             raise RuntimeError(
                 'libhrnet_hip.so not found at {} - build it with `python __graft_entry__.py` '
                 '(hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(LIB_PATH))
+        # PyTorch ships its own libamdhip64; the library must bind to THAT copy (same soname), or the process ends up
+        # with two HIP runtimes and this one's launches fail with "no ROCm-capable device is detected" (seen when
+        # `python __graft_entry__.py smoke` loaded the library before anything had imported torch)
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             fn = getattr(l, name)

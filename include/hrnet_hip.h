@@ -580,6 +580,22 @@ int hrnet_deform_conv_backward(const float* input, const float* offset, const fl
                                int dh, int dw, int groups, int deformable_groups,
                                hr_stream_t stream);
 
+/* Modulated deformable convolution (DCNv2): the same op with every sample multiplied by
+ * mask [B, deformable_groups*kh*kw, Ho, Wo]. Replaces DCN.modulated_deform_conv_forward / _backward bound by
+ * lib/deformable_conv/functions/modulated_deform_conv_func.py:25-33,44-56 (src/modulated_deform_conv.h:10-86,
+ * src/cuda/modulated_deform_conv_cuda.cu:20-285, kernels src/cuda/modulated_deform_im2col_cuda.cuh:128-330).
+ * backward: grad_input is zeroed inside; grad_mask like mask; scratch as for hrnet_deform_conv_backward. */
+int hrnet_modulated_deform_conv_forward(const float* input, const float* offset, const float* mask,
+                                        const float* weight, const float* bias, float* output, int B, int C,
+                                        int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                                        int dh, int dw, int groups, int deformable_groups, hr_stream_t stream);
+int hrnet_modulated_deform_conv_backward(const float* input, const float* offset, const float* mask,
+                                         const float* weight, const float* grad_output, float* grad_input,
+                                         float* grad_offset, float* grad_mask, float* grad_weight,
+                                         float* grad_bias, float* scratch, int B, int C, int H, int W, int Co,
+                                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                         int groups, int deformable_groups, hr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

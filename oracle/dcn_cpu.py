@@ -134,9 +134,10 @@ def deform_conv_backward(input, offset, weight, grad_output, stride, padding, di
     return grad_input, grad_offset, grad_weight, grad_bias
 
 
-def deform_conv_torch(input, offset, weight, bias, stride, padding, dilation, groups, DG):
+def deform_conv_torch(input, offset, weight, bias, stride, padding, dilation, groups, DG, mask=None):
     """The forward in differentiable torch ops (any float dtype) - autograd provides a second,
-    independent statement of the gradients."""
+    independent statement of the gradients. mask [B, DG*K, Ho, Wo]: the modulated form (DCNv2,
+    modulated_deform_im2col_cuda.cuh:128-193: column = sample * mask)."""
     import torch
     B, C, H, W = input.shape
     Co, Cg, kh, kw = weight.shape
@@ -163,6 +164,8 @@ def deform_conv_torch(input, offset, weight, bias, stride, padding, dilation, gr
         idx = (ih.clamp(0, H - 1) * W + iw.clamp(0, W - 1)).reshape(B, C, K, Ho * Wo)
         v = torch.gather(flat, 3, idx).reshape(B, C, K, Ho, Wo)
         cols = cols + torch.where(ok, wt * v, torch.zeros_like(v))
+    if mask is not None:
+        cols = cols * mask.reshape(B, DG, K, Ho, Wo).repeat_interleave(cpd, dim=1)
     Og = Co // groups
     outs = []
     for g in range(groups):
@@ -173,3 +176,74 @@ def deform_conv_torch(input, offset, weight, bias, stride, padding, dilation, gr
     if bias is not None:
         out = out + bias.reshape(1, Co, 1, 1)
     return out
+
+
+# ---- modulated deformable convolution (DCNv2) ------------------------------------------------------------------------
+# Reference: lib/deformable_conv/src/cuda/modulated_deform_im2col_cuda.cuh:128-193 (column = bilinear sample * mask,
+# mask channel = deformable group * K + tap), :196-257 (col2im: the scattered input gradient carries the mask),
+# :259-330 (coordinate kernel: offset gradient carries the mask, grad_mask = sum over the group's channels of
+# d loss / d column * unmasked sample); host modulated_deform_conv_cuda.cu:20-285 (shapes, bias, groups). CUDA-only
+# like v1; pinned by the reference test.py's invariants for the modulated op (zero offsets + unit mask == nn.Conv2d,
+# test.py:69-110; identity kernel 142-181; im2col_step 219-260, 304-349; gradcheck 405-434) in tests/test_dcn_oracle.py.
+def _mask_per_channel(mask, B, C, DG, K, Ho, Wo):
+    return np.repeat(mask.reshape(B, DG, K, Ho, Wo), C // DG, axis=1)                  # [B,C,K,Ho,Wo]
+
+
+def modulated_deform_conv_forward(input, offset, mask, weight, bias, stride, padding, dilation, groups, DG):
+    Co, Cg, kh, kw = weight.shape
+    B, C, H, W = input.shape
+    cols = deform_columns(input, offset, kh, kw, stride, padding, dilation, DG)
+    Ho, Wo = cols.shape[-2:]
+    cols = cols * _mask_per_channel(mask, B, C, DG, kh * kw, Ho, Wo)
+    Og = Co // groups
+    out = np.zeros((B, Co, Ho, Wo), dtype=input.dtype)
+    for g in range(groups):
+        wg = weight[g * Og:(g + 1) * Og].reshape(Og, Cg * kh * kw)
+        cg = cols[:, g * Cg:(g + 1) * Cg].reshape(B, Cg * kh * kw, Ho * Wo)
+        out[:, g * Og:(g + 1) * Og] = np.einsum('ok,bkp->bop', wg, cg).reshape(B, Og, Ho, Wo)
+    if bias is not None:
+        out += bias.reshape(1, Co, 1, 1)
+    return out
+
+
+def modulated_deform_conv_backward(input, offset, mask, weight, grad_output, stride, padding, dilation, groups, DG):
+    """returns grad_input, grad_offset, grad_mask, grad_weight, grad_bias"""
+    Co, Cg, kh, kw = weight.shape
+    B, C, H, W = input.shape
+    K = kh * kw
+    Og = Co // groups
+    cols_u = deform_columns(input, offset, kh, kw, stride, padding, dilation, DG)      # unmasked samples
+    Ho, Wo = cols_u.shape[-2:]
+    m = _mask_per_channel(mask, B, C, DG, K, Ho, Wo)
+    cols = cols_u * m
+    grad_weight = np.zeros_like(weight)
+    gcols = np.zeros_like(cols)                               # d loss / d (masked) columns
+    for g in range(groups):
+        go = grad_output[:, g * Og:(g + 1) * Og].reshape(B, Og, Ho * Wo)
+        cg = cols[:, g * Cg:(g + 1) * Cg].reshape(B, Cg * K, Ho * Wo)
+        grad_weight[g * Og:(g + 1) * Og] = np.einsum('bop,bkp->ok', go, cg).reshape(Og, Cg, kh, kw)
+        wg = weight[g * Og:(g + 1) * Og].reshape(Og, Cg * K)
+        gcols[:, g * Cg:(g + 1) * Cg] = np.einsum('ok,bop->bkp', wg, go).reshape(B, Cg, K, Ho, Wo)
+    grad_bias = grad_output.sum(axis=(0, 2, 3))
+    cpd = C // DG
+    grad_mask = (gcols * cols_u).reshape(B, DG, cpd, K, Ho, Wo).sum(axis=2).reshape(mask.shape)
+    gs = gcols * m                                            # d loss / d sample
+    h, w = _sample_positions(offset, (B, Ho, Wo), kh, kw, stride, padding, dilation, DG)
+    hC, wC = np.repeat(h, cpd, axis=1), np.repeat(w, cpd, axis=1)
+    cs, inside, (lh, lw, hh, hw) = _corners(hC, wC, H, W)
+    bi = np.broadcast_to(np.arange(B).reshape(B, 1, 1, 1, 1), hC.shape)
+    ci = np.broadcast_to(np.arange(C).reshape(1, C, 1, 1, 1), hC.shape)
+    grad_input = np.zeros_like(input)
+    vals = []
+    for (ih, iw, wt, ok) in cs:
+        ok = ok & inside
+        ihc, iwc = np.clip(ih, 0, H - 1), np.clip(iw, 0, W - 1)
+        np.add.at(grad_input, (bi[ok], ci[ok], ihc[ok], iwc[ok]), (gs * wt)[ok])
+        vals.append(np.where(ok, input[bi, ci, ihc, iwc], 0))
+    v1, v2, v3, v4 = vals
+    dh = np.where(inside, -hw * v1 - lw * v2 + hw * v3 + lw * v4, 0)
+    dw = np.where(inside, -hh * v1 + hh * v2 - lh * v3 + lh * v4, 0)
+    gh = (gs * dh).reshape(B, DG, cpd, K, Ho, Wo).sum(axis=2)
+    gw = (gs * dw).reshape(B, DG, cpd, K, Ho, Wo).sum(axis=2)
+    grad_offset = np.stack([gh, gw], axis=3).reshape(offset.shape)
+    return grad_input, grad_offset, grad_mask, grad_weight, grad_bias

@@ -206,3 +206,84 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(RuntimeError, match='deformable_groups'):
         DeformConvFunction.apply(z(1, 4, 4, 4, device=DEV), z(1, 54, 4, 4, device=DEV), z(4, 4, 3, 3, device=DEV),
                                  None, 1, 1, 1, 1, 3, 64)
+
+
+# ---- modulated form (DCNv2; reference functions/modulated_deform_conv_func.py, modules/modulated_deform_conv.py) ------
+def _mrun(c, with_grad=False, seed=9, im2col_step=64):
+    from deformable_conv import ModulatedDeformConvFunction
+    t = {k: torch.from_numpy(c[k]).to(DEV).requires_grad_(with_grad) for k in ('input', 'offset', 'mask', 'weight', 'bias')}
+    out = ModulatedDeformConvFunction.apply(t['input'], t['offset'], t['mask'], t['weight'], t['bias'], c['stride'],
+                                            c['padding'], c['dilation'], c['groups'], c['DG'], im2col_step)
+    if not with_grad:
+        return out.cpu().numpy()
+    go = np.random.default_rng(seed).standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(go).to(DEV))
+    return out.detach().cpu().numpy(), go, {k: v.grad.cpu().numpy() for k, v in t.items()}
+
+
+def _mcase(seed, *shape, **kw):
+    c = _case(seed, *shape, **kw)
+    B, _, Ho, Wo = c['offset'].shape
+    k = c['weight'].shape[2]
+    c['mask'] = np.random.default_rng(seed + 7).random((B, c['DG'] * k * k, Ho, Wo)).astype(np.float32)
+    return c
+
+
+MCASES = [
+    (2, 4, 4, 4, 4, 3, 2, 1, 1, 1, 1),          # the reference test's shape (test.py:69-110)
+    (2, 4, 9, 7, 6, 3, 1, 2, 2, 1, 1),          # stride 2, ragged size, two deformable groups
+    (1, 6, 11, 13, 4, 3, 2, 3, 1, 2, 2),        # deformable groups straddle conv groups
+    (3, 21, 16, 16, 21, 3, 1, 21, 1, 6, 6),     # PoseAggr geometry
+    (1, 8, 10, 10, 40, 3, 1, 1, 1, 1, 1),       # > 32 output channels
+]
+
+
+@pytest.mark.parametrize('shape', MCASES)
+def test_modulated_forward_and_backward_match_the_oracle(shape):
+    c = _mcase(31 + sum(shape), *shape)
+    out, go, g = _mrun(c, True)
+    c64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    ref = D.modulated_deform_conv_forward(c64['input'], c64['offset'], c64['mask'], c64['weight'], c64['bias'],
+                                          c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    gi, goff, gm, gw, gb = D.modulated_deform_conv_backward(c64['input'], c64['offset'], c64['mask'], c64['weight'],
+                                                            go.astype(np.float64), c['stride'], c['padding'],
+                                                            c['dilation'], c['groups'], c['DG'])
+    for name, want in (('input', gi), ('offset', goff), ('mask', gm), ('weight', gw), ('bias', gb)):
+        s = max(1.0, float(np.abs(want).max()))
+        assert np.abs(g[name] - want).max() < 5e-5 * s, name
+
+
+def test_modulated_invariants_of_the_reference_test():
+    """zero offsets + unit mask == nn.Conv2d incl. groups (test.py:69-110); unit mask == the v1 operator, forward and
+    gradients; im2col_step changes nothing (test.py:219-260, 304-349); the Pack module starts as half a convolution"""
+    from deformable_conv import DeformConvFunction, ModulatedDeformConvPack
+    c = _mcase(41, 2, 4, 8, 8, 6, 3, 2, 2, 1, 1, 1)
+    c['offset'][:] = 0
+    c['mask'][:] = 1
+    out = _mrun(c)
+    ref = F.conv2d(torch.from_numpy(c['input']), torch.from_numpy(c['weight']), torch.from_numpy(c['bias']), 1, 1, 1, 2)
+    assert np.abs(out - ref.numpy()).max() < 1e-5
+    c = _mcase(42, 2, 4, 8, 8, 6, 3, 2, 2, 1, 1, 1)
+    c['mask'][:] = 1
+    a, go, ga = _mrun(c, True, im2col_step=1)
+    b, _, gb = _mrun(c, True, im2col_step=2)
+    assert np.array_equal(a, b)
+    for k in ('offset', 'mask', 'weight', 'bias'):
+        assert np.array_equal(ga[k], gb[k]), k
+    v1, _, g1 = _run({k: v for k, v in c.items() if k != 'mask'}, True)
+    assert np.abs(a - v1).max() < 1e-5
+    for k in ('offset', 'weight', 'bias'):
+        assert np.abs(ga[k] - g1[k]).max() < 1e-4 * max(1.0, float(np.abs(g1[k]).max())), k
+    assert np.abs(ga['input'] - g1['input']).max() < 1e-4 * max(1.0, float(np.abs(g1['input']).max()))
+    torch.manual_seed(0)
+    m = ModulatedDeformConvPack(4, 6, 3, 1, 1, deformable_groups=2).to(DEV)
+    assert sorted(k for k, _ in m.named_parameters()) == ['bias', 'conv_offset_mask.bias', 'conv_offset_mask.weight', 'weight']
+    x = torch.randn(2, 4, 8, 8, device=DEV)
+    want = 0.5 * F.conv2d(x, m.weight, None, 1, 1) + m.bias.view(1, -1, 1, 1)          # sigmoid(0) = 0.5 on every sample
+    assert float((m(x) - want).abs().max()) < 1e-5
+    with pytest.raises(ValueError, match='mask shape'):
+        from deformable_conv import ModulatedDeformConvFunction
+        z = torch.zeros
+        ModulatedDeformConvFunction.apply(z(1, 4, 4, 4, device=DEV), z(1, 18, 4, 4, device=DEV), z(1, 8, 4, 4, device=DEV),
+                                          z(4, 4, 3, 3, device=DEV), None, 1, 1, 1, 1, 1, 64)

@@ -134,3 +134,97 @@ def test_vectorised_oracle_equals_the_reference_loops(DG, stride, pad, dil):
     gcol = np.einsum('ok,bop->kbp', wgt.reshape(Co, -1), go.reshape(B, Co, -1)).reshape(C * kh * kw, B, Ho, Wo)
     assert np.abs(L.col2im(gcol, off, im.shape, kh, kw, st, pd, dl, DG) - gi).max() < 1e-10
     assert np.abs(L.col2im_coord(gcol, im, off, kh, kw, st, pd, dl, DG) - goff).max() < 1e-10
+
+
+# ---- modulated form (DCNv2): the invariants the reference's test.py checks for it -----------------------------------
+def _mcase(seed, **kw):
+    c = _case(seed, **kw)
+    rng = np.random.default_rng(seed + 100)
+    B, _, Ho, Wo = c['offset'].shape
+    k = c['weight'].shape[2]
+    c['mask'] = rng.random((B, c['DG'] * k * k, Ho, Wo))
+    return c
+
+
+def _margs(c):
+    return (c['input'], c['offset'], c['mask'], c['weight'], c['bias'], c['stride'], c['padding'], c['dilation'],
+            c['groups'], c['DG'])
+
+
+@pytest.mark.parametrize('groups,stride,pad,dil', [(2, 1, 1, 1), (1, 2, 1, 1), (1, 1, 3, 3)])
+def test_modulated_zero_offset_unit_mask_is_plain_convolution(groups, stride, pad, dil):
+    """reference test.py:69-110 (check_mdconv_zero_offset: offsets 0, mask 1 -> nn.Conv2d); a constant mask m scales the
+    bias-free part by m"""
+    c = _mcase(11, H=9, W=8, groups=groups, stride=stride, pad=pad, dil=dil)
+    c['offset'][:] = 0
+    c['mask'][:] = 1.0
+    out = D.modulated_deform_conv_forward(*_margs(c))
+    conv = lambda bias: F.conv2d(torch.from_numpy(c['input']), torch.from_numpy(c['weight']), bias, stride, pad, dil,
+                                 groups).numpy()
+    assert np.abs(out - conv(torch.from_numpy(c['bias']))).max() < 1e-10
+    c['mask'][:] = 0.5
+    out = D.modulated_deform_conv_forward(*_margs(c))
+    assert np.abs(out - (0.5 * conv(None) + c['bias'].reshape(1, -1, 1, 1))).max() < 1e-10
+
+
+def test_modulated_unit_mask_equals_v1_and_identity_kernel():
+    """mask == 1: the v1 operator (forward and every gradient); identity kernel: reference test.py:142-181"""
+    c = _mcase(12, groups=2, DG=2)
+    c['mask'][:] = 1.0
+    v1 = {k: v for k, v in c.items() if k != 'mask'}
+    assert np.abs(D.modulated_deform_conv_forward(*_margs(c)) - D.deform_conv_forward(**v1)).max() < 1e-12
+    go = np.random.default_rng(5).standard_normal(D.deform_conv_forward(**v1).shape)
+    gi, goff, gm, gw, gb = D.modulated_deform_conv_backward(c['input'], c['offset'], c['mask'], c['weight'], go,
+                                                            c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    ri, roff, rw, rb = D.deform_conv_backward(c['input'], c['offset'], c['weight'], go, c['stride'], c['padding'],
+                                              c['dilation'], c['groups'], c['DG'])
+    for a, b in ((gi, ri), (goff, roff), (gw, rw), (gb, rb)):
+        assert np.abs(a - b).max() < 1e-12
+    c['offset'][:] = 0
+    c['weight'][:] = 0
+    c['bias'][:] = 0
+    Co = c['weight'].shape[0]
+    for q in range(Co):
+        c['weight'][q, q % (Co // 2), 1, 1] = 1.0
+    assert np.abs(D.modulated_deform_conv_forward(*_margs(c)) - c['input']).max() < 1e-12
+
+
+@pytest.mark.parametrize('groups,DG,dil', [(1, 1, 1), (2, 2, 1), (1, 4, 2)])
+def test_modulated_explicit_backward_matches_autograd_and_finite_differences(groups, DG, dil):
+    """the explicit col2im / coordinate / mask formulas against autograd of the torch form, and the torch form against
+    finite differences with the reference's gradcheck settings (test.py:405-434: float64, eps 1e-3, atol 1e-3, rtol 1e-2)"""
+    c = _mcase(13, groups=groups, DG=DG, dil=dil, pad=dil)
+    t = {k: torch.from_numpy(c[k]).requires_grad_(True) for k in ('input', 'offset', 'mask', 'weight', 'bias')}
+    out = D.deform_conv_torch(t['input'], t['offset'], t['weight'], t['bias'], c['stride'], c['padding'], c['dilation'],
+                              c['groups'], c['DG'], mask=t['mask'])
+    assert np.abs(out.detach().numpy() - D.modulated_deform_conv_forward(*_margs(c))).max() < 1e-10
+    go = np.random.default_rng(6).standard_normal(tuple(out.shape))
+    out.backward(torch.from_numpy(go))
+    gi, goff, gm, gw, gb = D.modulated_deform_conv_backward(c['input'], c['offset'], c['mask'], c['weight'], go,
+                                                            c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    for name, got in (('input', gi), ('offset', goff), ('mask', gm), ('weight', gw), ('bias', gb)):
+        assert np.abs(got - t[name].grad.numpy()).max() < 1e-9, name
+
+
+def test_modulated_gradcheck_with_the_reference_tolerances():
+    """reference test.py:405-434: float64, eps=1e-3, atol=1e-3, rtol=1e-2 - through the EXPLICIT numpy forward / backward
+    (the geometry and offsets of the v1 check above, whose sample positions stay clear of the bilinear kinks)"""
+    c = _case(6, B=2, C=4, H=4, W=4, Co=4, groups=2, DG=1)
+    c['mask'] = np.random.default_rng(7).random((2, 9, 4, 4)) + 0.25
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input, offset, mask, weight, bias):
+            ctx.save_for_backward(input, offset, mask, weight)
+            return torch.from_numpy(D.modulated_deform_conv_forward(
+                input.numpy(), offset.numpy(), mask.numpy(), weight.numpy(), bias.numpy(), c['stride'], c['padding'],
+                c['dilation'], c['groups'], c['DG']))
+
+        @staticmethod
+        def backward(ctx, g):
+            i, o, m, w = (v.numpy() for v in ctx.saved_tensors)
+            r = D.modulated_deform_conv_backward(i, o, m, w, g.numpy(), c['stride'], c['padding'], c['dilation'],
+                                                 c['groups'], c['DG'])
+            return tuple(torch.from_numpy(np.ascontiguousarray(v)) for v in r)
+    args = [torch.from_numpy(c[k]).requires_grad_(True) for k in ('input', 'offset', 'mask', 'weight', 'bias')]
+    assert torch.autograd.gradcheck(Fn.apply, args, eps=1e-3, atol=1e-3, rtol=1e-2, raise_exception=True)
