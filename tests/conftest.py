@@ -14,6 +14,13 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle's threads: the box's CPU share (a one-GPU box gets 16 cores but reports 128 - 128 OpenMP threads
+    # on 16 cores spend their time spinning: the B=40 oracle step took 22 s there)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except Exception:
+        pass
     # the C-ABI library is built in-tree (hipcc cross-compiles without a GPU); build it when a fresh checkout
     # runs the tests before `python __graft_entry__.py`
     lib = os.path.join(REPO, 'hrnet-hand-pose-estimation_amd', 'csrc', 'libhrnet_hip.so')
