@@ -1,5 +1,7 @@
 // Convolution entry points: argument checks, tile choice, mode choice; the generic instantiation.
 // The device code lives in conv_body.h.
+#include <string.h>
+
 #include "conv_body.h"
 #include "conv_ring.h"
 
@@ -44,6 +46,7 @@ inline int launch_ring(const ConvArgs& a, int in_relu, hipStream_t s) {
   c.bs_y = a.bs_y; c.bs_mask = a.bs_mask; c.bs_scale = a.bs_scale; c.bs_shift = a.bs_shift;
   c.N = a.N; c.H = a.H; c.W = a.W; c.Cin = a.Cin; c.Cout = a.Cout; c.in_relu = in_relu;
   c.accumulate = a.accumulate; c.bs_store_masked = a.bs_store_masked;
+  c.x2 = a.x2; c.side = a.side;
   return hr_conv_ring_launch(c, s);
 }
 }  // namespace
@@ -211,6 +214,10 @@ int hr_launch_conv_sum(const HrOp& op, hipStream_t s) {
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
   a.in_relu = 1; a.upz = 0; a.accumulate = 0;
   a.Hz = H; a.Wz = W;
+  // the narrow branch convolutions: the residual sum inside the LDS-ring pipeline (round 4; conv_ring.hip, X2)
+  if (ks == 3 && (!a.stats || a.stats_atomic) && (!a.in_sums || a.in_beta == a.in_gamma + Cin) &&
+      hr_conv_ring_sum_supported(dtype, N, H, W, Cin, Cout))
+    return launch_ring(a, 1, s);
   const TileChoice tc = choose_tile(N, H, W, Cout, ks, 1, false, false);
   a.tiles_y = (H + tc.th - 1) / tc.th;
   a.tiles_x = (W + tc.tw - 1) / tc.tw;
@@ -324,6 +331,15 @@ extern "C" int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin,
   if (ks == 1 && stride == 1 && !upz && hr_gemm_pw_supported(dtype, Cin, Cout) &&
       (mode == CONV_FWD || mode == CONV_FWDB || mode == CONV_DG))
     return snprintf(buf, buflen, "gemm_pw_kernel");
+  if (ks == 3 && stride == 1 && !upz && mode == CONV_FWDS && hr_conv_ring_sum_supported(dtype, N, Ho, Wo, Cin, Cout)) {
+    // (the residual-sum form of the narrow instantiations: "..., false, true"; the batch-statistics mode decides at
+    // launch - HRNET_DETERMINISTIC=1 keeps the tile-walking body, which this name query cannot see)
+    char tmp[96];
+    hr_conv_ring_name(hr_conv_ring_supported(dtype, N, Ho, Wo, Cin, Cout, 0), 0, tmp, sizeof(tmp));
+    const int n = (int)strlen(tmp);
+    if (n > 1) tmp[n - 1] = 0;          // drop the closing '>'
+    return snprintf(buf, buflen, "%s, true>", tmp);
+  }
   if (ks == 3 && stride == 1 && !upz && hr_conv_ring_enabled()) {
     const int bsm = mode == CONV_BS ? 1 : 0;
     if ((bsm || mode == CONV_FWD || mode == CONV_GENERIC || mode == CONV_DG) &&

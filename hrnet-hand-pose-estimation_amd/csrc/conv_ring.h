@@ -18,6 +18,9 @@ struct HrRingConv {
   const void* bs_mask;
   const float* bs_scale;
   const float* bs_shift;
+  // residual-sum launches (hrnet_conv2d_sum on the narrow instantiations): input a = relu(bn(x) + x2), written to side
+  const void* x2;
+  void* side;
   float in_inv_count, in_eps;
   int N, H, W, Cin, Cout, in_relu, accumulate, bs_store_masked;
 };
@@ -26,6 +29,8 @@ int hr_conv_ring_enabled();
 // instantiation id (> 0) if conv_ring serves a 3x3 stride-1 pad-1 launch of this shape, else 0.
 // bs: an input-gradient launch (raw input) with backward statistics and / or accumulation into y
 int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout, int bs);
+// 1 if the residual-sum form (HrRingConv.x2 / side) is served for this shape: the resident-weight instantiations (1, 2)
+int hr_conv_ring_sum_supported(int dtype, int N, int H, int W, int Cin, int Cout);
 // statistics rows a backward-statistics launch of this shape writes (= its pixel walks)
 int hr_conv_ring_rows(int N, int H, int W, int Cin, int Cout);
 int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s);

@@ -28,6 +28,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "conv_ring.h"
 
@@ -48,6 +50,10 @@ struct RingArgs {
   const char* bs_mask;
   const float* bs_scale;
   const float* bs_shift;
+  // residual-sum launches (hrnet_conv2d_sum, template X2): the conv's input is a = relu(bn(x) + x2), formed while the
+  // stage is transformed in LDS and written to `side` once per pixel (by the first output-channel block)
+  const char* x2;        // [N,H,W,Cin] identity term
+  char* side;            // [N,H,W,Cin] the sum, for the next residual add and for backward
   float in_inv_count, in_eps;
   int N, H, W, Cin, Cout;
   int tiles_y, tiles_x, total_tiles, tpw, gx, gy;
@@ -108,9 +114,10 @@ struct RingCfg {
   static_assert(LANE_C == 8 || LANE_C == 16, "a lane stores 16-byte vectors");
 };
 
-template <int TH, int TW, int TI, int NB, int NW, int WPX, int R, int WCH, bool BS>
+template <int TH, int TW, int TI, int NB, int NW, int WPX, int R, int WCH, bool BS, bool X2 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
   using C = RingCfg<TH, TW, TI, NB, NW, WPX, R, WCH>;
+  static_assert(!X2 || (R == 3 && TI == 1 && !BS), "the residual-sum form: three slots, one image per tile, forward");
   __shared__ __attribute__((aligned(1024))) char lds[C::LDSB];
   char* xl = lds + C::XOFF;
   char* wl = lds + C::WOFF;
@@ -224,7 +231,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
       }
     }
   };
-  auto issue_stage = [&](int s) {
+  // X2: the identity term's 16 bytes of every piece this lane fetches, in REGISTERS from issue to transform (stage s
+  // in set s & 1: two stages are in flight between the two). Loaded by inline-asm global loads the compiler does not
+  // see (a load it tracked would get an `s_waitcnt vmcnt(0)` in front of its use and drain the ring); they are counted
+  // in `cnt` like every other vector-memory instruction, the stage's counted wait covers them, and an empty asm with
+  // the registers as "+v" operands behind that wait keeps their readers behind it.
+  V16 x2r[X2 ? 2 : 1][X2 ? C::KPX : 1];
+  auto issue_stage = [&](int s, auto par) {
+    constexpr int P = decltype(par)::value;
     const int slot = s % R;
     const int n = __builtin_amdgcn_readfirstlane(ci.n), ty = __builtin_amdgcn_readfirstlane(ci.ty),
               tx = __builtin_amdgcn_readfirstlane(ci.tx), ch = __builtin_amdgcn_readfirstlane(ci.ch);
@@ -234,11 +248,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
     for (int k = 0; k < C::KPX; ++k) {
       const int q = wv + k * NW;
       if (q < C::NPX) {
-        const unsigned vo = inside(hyx[k], n, iy0, ix0) ? (unsigned)(sbase + goff[k]) : OOB;
+        const bool ok = inside(hyx[k], n, iy0, ix0);
+        const unsigned vo = ok ? (unsigned)(sbase + goff[k]) : OOB;
         // (slots beyond the tile's halo stay out of the next ring slot; padding slots of a row get zeros)
         if ((q * 16 + pj) < C::HPX)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xl + slot * C::XSB + q * 1024), 16, vo, 0, 0, 0);
         ++cnt;
+        if constexpr (X2) {
+          // (every lane loads: a lane outside the image reads the tensor's first bytes and its value is never used)
+          const char* p2 = a.x2 + (ok ? (long long)(sbase + goff[k]) : 0ll);
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x2r[P][k]) : "v"(p2) : "memory");
+          ++cnt;
+        }
       }
     }
     if constexpr (!C::WRES) issue_w(ch, slot);
@@ -286,7 +307,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
     for (int ch = 0; ch < nch; ++ch) issue_w(ch, ch);
   }
   const int npro = S < R - 1 ? S : R - 1;
-  for (int s = 0; s < npro; ++s) issue_stage(s);
+  if (npro > 0) issue_stage(0, std::integral_constant<int, 0>{});
+  if (npro > 1) issue_stage(1, std::integral_constant<int, 1>{});
+  if constexpr (R > 3) {
+    if (npro > 2) issue_stage(2, std::integral_constant<int, 0>{});
+  }
   RSTAMP();
 
   if (has_aff) {
@@ -346,18 +371,52 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
   if (nch == 1) load_coef(0);
 
   // in-place transform of the stage the transform cursor points at (own pieces only)
-  auto transform = [&](int s) {
+  const auto rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(X2 ? a.side : a.y), 0, X2 ? (int)a.x_bytes : 0, 0x00020000);
+  const bool side_wg = X2 && n0 == 0;      // the first output-channel block of a walk writes the sum out
+  auto transform = [&](int s, auto par) {
+    constexpr int P = decltype(par)::value;
     const int slot = s % R;
     const int n = __builtin_amdgcn_readfirstlane(ct.n), ty = __builtin_amdgcn_readfirstlane(ct.ty),
               tx = __builtin_amdgcn_readfirstlane(ct.tx), ch = __builtin_amdgcn_readfirstlane(ct.ch);
+    if constexpr (X2) {
+      // (behind the stage's counted wait: the identity term's registers become readable here, not earlier)
+#pragma unroll
+      for (int k = 0; k < C::KPX; ++k) asm volatile("" : "+v"(x2r[P][k]));
+    }
     if (xf) {
       if (nch != 1) load_coef(ch);
       const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+      const int sbase = ((n * TI * a.H + iy0) * a.W + ix0) * pixB + ch * 64;
 #pragma unroll
       for (int k = 0; k < C::KPX; ++k) {
         const int q = wv + k * NW;
         if (q < C::NPX) {
           const bool ok = inside(hyx[k], n, iy0, ix0);
+          if constexpr (X2) {
+            // a = relu(scale * x + shift + x2), rounded once: what goes to LDS IS what goes to `side`
+            // (conv_body.h CONV_FWDS: the same arithmetic in the same order)
+            V16 v = v16_zero();
+            if ((q * 16 + pj) < C::HPX) {
+              const unsigned la = lds_x0 + (unsigned)(slot * C::XSB + q * 1024 + lane * 16);
+              asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(la) : "memory");
+              float f[8], g2[8];
+              v16_unpack<bf16_t>(v, f);
+              v16_unpack<bf16_t>(x2r[P][k], g2);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { f[j] = fmaf(f[j], sc[j], sh[j]) + g2[j]; f[j] = f[j] > 0.f ? f[j] : 0.f; }
+              v = ok ? v16_pack<bf16_t>(f) : v16_zero();
+              asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(v) : "memory");
+            }
+            if (side_wg) {
+              // centre (non-halo) pixels of the tile, once per pixel; every lane issues the store (the others beyond
+              // the descriptor's range), so that the instruction count below is exact
+              const int hy = (hyx[k] >> 10) & 0x3ff, hx = hyx[k] & 0x3ff;
+              const bool centre = ok && (q * 16 + pj) < C::HPX && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+              __builtin_amdgcn_raw_buffer_store_b128(v, rsd, centre ? (unsigned)(sbase + goff[k]) : OOB, 0, 0);
+              ++cnt;
+            }
+            continue;
+          }
           if ((q * 16 + pj) < C::HPX) {
             // (LDS accesses in inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of a ds_read of the address a
             // direct load wrote - it would drain the younger stages; the data is this lane's own and the counted
@@ -391,20 +450,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
   if (S > 0) {
     wait_vmcnt(cnt - get_mark(0));
     RSTAMP();
-    transform(0);
+    transform(0, std::integral_constant<int, 0>{});
   }
   lds_barrier();
   RSTAMP();
 
   f32x4 acc[C::FC][C::FP];
-  for (int i = 0; i < S; ++i) {
-    if (i + R - 1 < S) issue_stage(i + R - 1);
+  // one iteration; `par` = parity of i (compile time: it names the register set of the identity term, X2)
+  auto iteration = [&](int i, auto par) {
+    constexpr int P = decltype(par)::value;
+    // (R = 3: stage i + 2 has the parity of i; R = 2 / 4 are never instantiated with X2)
+    if (i + R - 1 < S) issue_stage(i + R - 1, std::integral_constant<int, (P + R - 1) & 1>{});
     if constexpr (R > 2) {
       // the stage after this one is transformed before this one's matrix work (its loads were issued two iterations ago)
       if (i + 1 < S) {
         wait_vmcnt(cnt - get_mark((i + 1) % R));
         RSTAMP();
-        transform(i + 1);
+        transform(i + 1, std::integral_constant<int, 1 - P>{});
       }
     }
     RSTAMP();
@@ -460,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
       // two slots: the next stage lands while this one's matrix work runs, and is transformed after it
       if (i + 1 < S) {
         wait_vmcnt(cnt - get_mark((i + 1) % R));
-        transform(i + 1);
+        transform(i + 1, std::integral_constant<int, 1 - P>{});
       }
     }
     if (ch == nch - 1) {
@@ -528,6 +590,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ring_kernel(RingArgs a) {
     cur_next(cc);
     lds_barrier();     // slot i % R is free; the transformed image of stage i + 1 is visible
     RSTAMP();
+  };
+  if constexpr (X2) {
+    for (int i = 0; i < S; i += 2) {
+      iteration(i, std::integral_constant<int, 0>{});
+      if (i + 1 < S) iteration(i + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    for (int i = 0; i < S; ++i) iteration(i, std::integral_constant<int, 0>{});
   }
 
   if (a.stats) {
@@ -662,6 +732,21 @@ int hr_conv_ring_supported(int dtype, int N, int H, int W, int Cin, int Cout, in
   return ring_plan(N, H, W, Cin, Cout, bs != 0).id;
 }
 
+// The residual-sum form is OFF by default: bit-identical to the tile-walking body, but inside the training step it loses (15.50-15.56 against 15.39-15.41 ms/step in three A/B
+// pairs: 48 more VGPRs per wave for the identity term and the side stores inside the ring). hrnet_conv_ring_sum_enable(1)
+// (or HRNET_RING_SUM=1 with HRNET_MEASURE=1) turns it on: tests/test_conv_ring_gpu.py, measurements.
+static int g_ring_sum = -1;
+extern "C" int hrnet_conv_ring_sum_enable(int on) {
+  const int prev = g_ring_sum < 0 ? hr_knob("HRNET_RING_SUM", 0) : g_ring_sum;
+  g_ring_sum = on;
+  return prev;
+}
+int hr_conv_ring_sum_supported(int dtype, int N, int H, int W, int Cin, int Cout) {
+  if (g_ring_sum < 0) g_ring_sum = hr_knob("HRNET_RING_SUM", 0);
+  const int id = (g_ring_sum && hr_conv_ring_enabled()) ? hr_conv_ring_supported(dtype, N, H, W, Cin, Cout, 0) : 0;
+  return (id == 1 || id == 2) ? 1 : 0;
+}
+
 int hr_conv_ring_rows(int N, int H, int W, int Cin, int Cout) {
   const RingPlan p = ring_plan(N, H, W, Cin, Cout, true);
   if (!p.id) return 0;
@@ -693,6 +778,10 @@ int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
   a.in_sums = c.in_sums; a.in_gb = c.in_gb; a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.stats = c.stats; a.in_inv_count = c.in_inv_count; a.in_eps = c.in_eps;
   a.bs_y = (const char*)c.bs_y; a.bs_mask = (const char*)c.bs_mask; a.bs_scale = c.bs_scale; a.bs_shift = c.bs_shift;
+  a.x2 = (const char*)c.x2; a.side = (char*)c.side;
+  const bool x2 = c.x2 != nullptr;
+  HR_REQUIRE(!x2 || (c.side && !bs && (p.id == 1 || p.id == 2) && (c.in_sums || c.in_scale)),
+             "conv_ring: the residual-sum form needs side, a BatchNorm term and a resident-weight instantiation (id %d)", p.id);
   a.N = c.N; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout;
   ring_grid(p, c.N, c.H, c.W, c.Cout, a.tiles_y, a.tiles_x, a.total_tiles, a.tpw, a.gx, a.gy);
   a.in_relu = c.in_relu; a.accumulate = c.accumulate; a.bs_store_masked = c.bs_store_masked;
@@ -704,7 +793,11 @@ int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
 #endif
   const unsigned grid = (unsigned)((a.gx * a.gy + 7) / 8 * 8);
 #define RING(BS_, NW_, ...) hipLaunchKernelGGL((conv_ring_kernel<__VA_ARGS__, BS_>), dim3(grid), dim3(NW_ * 64), 0, s, a)
-  if (!bs) {
+#define RINGX(NW_, ...) hipLaunchKernelGGL((conv_ring_kernel<__VA_ARGS__, false, true>), dim3(grid), dim3(NW_ * 64), 0, s, a)
+  if (x2) {
+    if (p.id == 1) RINGX(4, 16, 16, 1, 32, 4, 4, 3, 1);
+    else RINGX(4, 8, 16, 1, 32, 4, 4, 3, 2);
+  } else if (!bs) {
     switch (p.id) {
       case 1: RING(false, 4, 16, 16, 1, 32, 4, 4, 3, 1); break;
       case 2: RING(false, 4, 8, 16, 1, 32, 4, 4, 3, 2); break;
@@ -722,5 +815,6 @@ int hr_conv_ring_launch(const HrRingConv& c, hipStream_t s) {
     }
   }
 #undef RING
+#undef RINGX
   return hr_check_launch("conv_ring");
 }

@@ -88,6 +88,7 @@ _SIGS = {
     'hrnet_conv_ring_supported': [_c_int] * 6,
     'hrnet_conv_rows_bwdstats': [_c_int] * 8,
     'hrnet_conv_route': [_c_int] * 8,
+    'hrnet_conv_ring_sum_enable': [_c_int],
     'hrnet_conv_tiles': [_c_int] * 6,
     'hrnet_conv_tiles_bwdstats': [_c_int] * 6,
     'hrnet_conv_tile_walk': [_c_int] * 8 + [_ip],
@@ -152,7 +153,7 @@ _SIGS = {
     'hrnet_modulated_deform_conv_backward': [_c_vp] * 11 + [_c_int] * 15 + [_c_vp],
 }
 # plain-int helpers (no error code semantics)
-_PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_route', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
+_PLAIN = {'hrnet_abi_version', 'hrnet_ew_table_blocks', 'hrnet_conv_rows_bwdstats', 'hrnet_conv_route', 'hrnet_conv_ring_sum_enable', 'hrnet_conv_ring_enable', 'hrnet_conv_ring_supported', 'hrnet_conv_tiles', 'hrnet_conv_tile_walk', 'hrnet_conv_tiles_bwdstats', 'hrnet_wgrad_splits', 'hrnet_wgrad_tiles', 'hrnet_wgrad_blocks_per_split', 'hrnet_bwd_fused_supported', 'hrnet_bwd_fused_splits', 'hrnet_bwd_fused_kernel_name', 'hrnet_reduce_blocks',
           'hrnet_pack_blocks', 'hrnet_bwd_pw_supported', 'hrnet_bwd_pw_rows_supported', 'hrnet_bwd_pw_splits', 'hrnet_bwd_pw_kernel_name',
           'hrnet_conv_kernel_name', 'hrnet_wgrad_kernel_name', 'hrnet_conv_mode', 'hrnet_deform_conv_wgrad_blocks',
           'hrnet_head_mix_rows', 'hrnet_head_mix_supported'}

@@ -186,6 +186,9 @@ int hrnet_conv_rows_bwdstats(int dtype, int N, int Ho, int Wo, int Cin, int Cout
  * 1 = tile-walking body; the rows buffer above is sized for that family, so the op keeps the decision and a later
  * hrnet_conv_ring_enable() cannot change how many rows the launch writes (it fails instead). 0 = decide at launch. */
 int hrnet_conv_route(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride);
+/* hrnet_conv2d_sum on the LDS-ring pipeline for the narrow branch layers (bf16, 3x3, 32 / 64 input channels): off by
+ * default (measured slower inside the training step), on = 1; returns the previous setting */
+int hrnet_conv_ring_sum_enable(int on);
 
 /* name of the kernel instantiation chosen for a shape, as rocprofv3 demangles it (returns length) */
 int hrnet_conv_kernel_name(int dtype, int N, int Ho, int Wo, int Cin, int Cout, int ks, int stride, int upz,

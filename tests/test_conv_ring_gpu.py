@@ -298,3 +298,79 @@ def test_recorded_backward_statistics_launch_keeps_its_kernel_family():
         run(2, rows_ring)
     run(1, rows_walk)
     C.call('hrnet_conv_ring_enable', 1)
+
+
+SUM_CASES = [
+    # N, H, W, Cin, Cout, BatchNorm given as
+    (70, 64, 64, 32, 32, 'sums'),      # > 512 tiles: several tiles per workgroup, both register sets of the identity term
+    (3, 20, 37, 32, 32, 'arrays'),     # tiles overhang the map on both axes
+    (1, 16, 16, 32, 32, 'sums'),       # one tile per workgroup (a single stage)
+    (40, 32, 32, 64, 64, 'sums'),      # two K chunks per tile, two output-channel blocks (the second must not write the sum)
+    (2, 24, 50, 64, 64, 'arrays'),
+    (5, 17, 16, 64, 32, 'sums'),       # an odd number of stages per workgroup
+]
+
+
+@pytest.mark.parametrize('case', SUM_CASES)
+def test_ring_conv_with_the_residual_sum_matches_the_tile_walking_body(case):
+    """hrnet_conv2d_sum on the LDS-ring pipeline (round 4): a = relu(bn(x) + x2) formed while a stage is transformed in
+    LDS (the identity term in registers from issue to transform), written to `side` once per pixel, y = conv(a) with
+    its batch statistics - against the tile-walking body (bit-identical `side` and y) and torch
+    (pose_hrnet.py:54-55 + :44 of the next block)."""
+    hh, C = _h(), _C()
+    N, H, W, Cin, Cout, mode = case
+    assert C.call('hrnet_conv_ring_enable', 1) is not None
+    g = torch.Generator().manual_seed(3 + N + Cin + Cout + H)
+    x = _q(torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.3)
+    x2 = _q(torch.randn(N, Cin, H, W, generator=g))
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9))
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.rand(Cin, generator=g) - 0.5
+    cnt = float(N * H * W)
+    s1, s2 = x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))
+    frac = torch.rand(8, 1, generator=g).double()
+    frac /= frac.sum()
+    sums = torch.stack([frac * s1[None], frac * s2[None]], 1).float().contiguous()
+    s1f, s2f = sums[:, 0].double().sum(0), sums[:, 1].double().sum(0)
+    mean = s1f / cnt
+    invstd = 1.0 / torch.sqrt((s2f / cnt - mean * mean).clamp_min(0).float() + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean.float() * scale
+    a_ref = _q(F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + x2))
+    y_ref = F.conv2d(a_ref, w, None, padding=1)
+    wp, _, _ = hh.pack_weights(w, DT)
+    xd, x2d = hh.nhwc(x, DT), hh.nhwc(x2, DT)
+    gb = torch.cat([gamma, beta]).to(hh.DEV).contiguous()          # contiguous gamma | beta: what the ring form takes
+    sums_d, scale_d, shift_d = sums.to(hh.DEV), scale.to(hh.DEV), shift.to(hh.DEV)
+    outs = []
+    prev_sum = C.call('hrnet_conv_ring_sum_enable', 1)      # (off by default: slower inside the training step)
+    for ring in (1, 0):
+        C.call('hrnet_conv_ring_enable', ring)
+        side = torch.full((N, H, W, Cin), float('nan'), dtype=DT, device=hh.DEV)
+        y = torch.full((N, H, W, Cout), float('nan'), dtype=DT, device=hh.DEV)
+        st = torch.zeros(8, 2, Cout, dtype=torch.float32, device=hh.DEV)
+        if mode == 'sums':
+            C.call('hrnet_conv2d_sum', 1, xd.data_ptr(), x2d.data_ptr(), wp.data_ptr(), None, None, sums_d.data_ptr(),
+                   gb.data_ptr(), gb.data_ptr() + 4 * Cin, 1.0 / cnt, 1e-5, side.data_ptr(), y.data_ptr(), st.data_ptr(), 1,
+                   N, H, W, Cin, Cout, 3, C.stream_ptr())
+        else:
+            C.call('hrnet_conv2d_sum', 1, xd.data_ptr(), x2d.data_ptr(), wp.data_ptr(), scale_d.data_ptr(), shift_d.data_ptr(),
+                   None, None, None, 0.0, 0.0, side.data_ptr(), y.data_ptr(), st.data_ptr(), 1, N, H, W, Cin, Cout, 3,
+                   C.stream_ptr())
+        hh.sync()
+        outs.append((side, y, st.double().sum(0).cpu()))
+    C.call('hrnet_conv_ring_enable', 1)
+    (sd1, y1, st1), (sd0, y0, st0) = outs
+    assert not torch.isnan(sd1.float()).any() and not torch.isnan(y1.float()).any()
+    assert torch.equal(sd1.view(torch.int16), sd0.view(torch.int16)), 'the sum written out differs from the tile-walking body'
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), 'ring and tile-walking bodies differ'
+    assert hh.rel_err(hh.from_nhwc(sd1, Cin), a_ref) <= 2.0 ** -7
+    assert hh.rel_err(hh.from_nhwc(y1, Cout), y_ref) <= 2 * TOL + 1e-2
+    assert float((st1 - st0).abs().max() / st0.abs().max()) <= 1e-5
+    # the kernel really is the ring's (a name query of the same shape says so)
+    import ctypes
+    buf = ctypes.create_string_buffer(160)
+    C.call('hrnet_conv_kernel_name', 1, N, H, W, Cin, Cout, 3, 1, 0, 5, buf, 160)
+    assert buf.value.decode().startswith('conv_ring_kernel<') and buf.value.decode().endswith('false, true>'), buf.value
+    C.call('hrnet_conv_ring_sum_enable', prev_sum)
+    C.call('hrnet_conv_kernel_name', 1, N, H, W, Cin, Cout, 3, 1, 0, 5, buf, 160)
+    assert prev_sum != 0 or buf.value.decode().startswith('conv_fwds_kernel<'), buf.value
