@@ -668,7 +668,9 @@ inline RingPlan ring_plan_all(int N, int H, int W, int Cin, int Cout, bool bs) {
   static const int wide8 = hr_knob("HRNET_RING_TI8", 4);   // (measurement: 2 or 4)
   static const int wide16 = hr_knob("HRNET_RING_TI16", 1);   // (measurement: 1 or 2)
   if (Cin % 32 != 0 || Cout % 16 != 0 || Cin > HR_RING_MAXC) return RingPlan{0, 0, 0, 0, 0, 0};
-  if (!bs && Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 1, 32, 2};
+  // (one workgroup per CU for the 32-channel instantiation: 256 workgroups of 80 KB leave room for the other lanes'
+  // workgroups on every CU - 15.32-15.35 against 15.36-15.39 ms/step with two per CU, round 4)
+  if (!bs && Cin == 32 && Cout <= 32 && H >= 16 && W >= 16) return RingPlan{1, 16, 16, 1, 32, 1};
   if (!bs && Cin == 64 && Cout >= 32 && H >= 16 && W >= 16) return RingPlan{2, 8, 16, 1, 32, 2};
   if (Cin >= 96 && Cout >= 64 && H == 8 && W == 8) return wide8 == 2 ? RingPlan{5, 8, 8, 2, 64, 0} : RingPlan{4, 8, 8, 4, 64, 0};
   if (Cin >= 96 && Cout >= 64 && H == 16 && W == 16 && wide16 == 2) return RingPlan{6, 16, 16, 2, 64, 0};

@@ -4,7 +4,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final_r04
 mkdir -p $O
-python bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/r04_bench_final.json
+SECONDS=0; python bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/r04_bench_final.json; echo "default bench wall: $SECONDS s"
 echo "default done: $(python -c "import json;d=json.load(open('$O/r04_bench_final.json'));print(d['ms_per_step'], d['value'], d.get('selfcheck'), d.get('dp_mode_ms_per_step_1gpu'))")"
 if [ "$1" != "quick" ]; then
 python bench.py --mode infer --dtype fp32 --no-cpu-baseline --no-roofline > $O/c2_fp32.log 2>&1; tail -1 $O/c2_fp32.log > $O/c2_fp32.json
