@@ -321,7 +321,11 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
   };
   constexpr int NS = XG + XA;
   constexpr int NKW = (BM / KSTEP) / KSPLIT;                       // weight-gradient k-steps of one wave
-  constexpr int NSLOT = 9 + (NKW <= 8 ? NKW : 0);                  // issue slots: the 9 taps (+ the weight-gradient k-steps)
+#ifndef HR_FUSED_LOAD_SLOTS
+#define HR_FUSED_LOAD_SLOTS 0     // measurement builds: n > 0 = the next tile's loads are all issued within the first n taps of the input-gradient phase (round 4: n = 9 / 5 / 3 change nothing, 15.33-15.35 against 15.26-15.31 ms/step - the wait at the top of a tile is not a matter of when its loads were issued)
+#endif
+  constexpr bool WSLOTS = HR_FUSED_LOAD_SLOTS == 0 && NKW <= 8;     // the weight-gradient k-steps are issue slots too
+  constexpr int NSLOT = HR_FUSED_LOAD_SLOTS > 0 ? HR_FUSED_LOAD_SLOTS : 9 + (WSLOTS ? NKW : 0);   // issue slots: the 9 taps (+ the weight-gradient k-steps)
   auto load_step = [&](auto sc) {       // step s < XG: dz + y vector s; else x vector s - XG
     constexpr int s_ = decltype(sc)::value;
     if constexpr (s_ < XG) load_g(std::integral_constant<int, s_>{});
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
           // this tap's share of the next tile's loads; vector-memory instructions may not move across (everything
           // else may): the requests enter the memory pipe evenly while the matrix pipe works
           __builtin_amdgcn_sched_barrier(0x38F);
-          switch (s_ / NKK) {
+          if (s_ / NKK < NSLOT) switch (s_ / NKK) {
 #define LS(SL) case SL: load_steps(std::integral_constant<int, (SL * NS) / NSLOT>{}, std::integral_constant<int, ((SL + 1) * NS) / NSLOT>{}); break;
             LS(0) LS(1) LS(2) LS(3) LS(4) LS(5) LS(6) LS(7) LS(8)
 #undef LS
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_fused_kernel(BwdArgs a) {
           }
           __builtin_amdgcn_sched_group_barrier(0x008, BPW * MF, 0);
         }
-        if constexpr (NKW <= 8) {
+        if constexpr (WSLOTS) {
           if (tp == 8) {
             __builtin_amdgcn_sched_barrier(0x38F);
             switch (i) {

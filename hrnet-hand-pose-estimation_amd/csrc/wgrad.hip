@@ -440,7 +440,13 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   // for 1x1 tiles, and only when every split walks the same number of tiles (an uneven split costs
   // 20-30 %). Each split costs one f32 slab of Cout*taps*Cin written and re-read by hrnet_wgrad_reduce.
   static const int wdiv = hr_knob("HRNET_WGRAD_DIV", 1);   // (measurement override)
-  const int target = (ks == 1 ? 1024 : 512) / wdiv;
+  int target = (ks == 1 ? 1024 : 512) / wdiv;
+  // 3x3 launches with plenty of pixel tiles per output block (w48's 96-channel branch on 48x36 maps: 288 tiles x 6
+  // blocks) take half as many workgroups: every workgroup ends with ~18 K float atomics into the gradient (10 us of a
+  // 25 us launch at two tiles per workgroup, scratch/wgrad_atomic_micro.py), so twice the tiles per workgroup halve that
+  // share - w48 29.92 -> 29.40 ms/step; w32's deferred launches (64 tiles x 8 blocks) stay where they are
+  static const int bigt = hr_knob("HRNET_WGRAD_BIG_TILES", 1024);   // (measurement: 0 = off)
+  if (ks == 3 && bigt > 0 && (long long)tiles * gy * gz >= bigt) target /= 2;
   int ns = target / (gy * gz);
   if (ns < 1) ns = 1;
   if (ns > 512) ns = 512;

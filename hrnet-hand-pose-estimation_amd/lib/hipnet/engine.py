@@ -1302,9 +1302,17 @@ class Plan(object):
         if not self.training or _knob('HRNET_FUSED_BWD', '1') == '0':
             return out
         T, L = self.tape, self.tape_lanes
-        # (the 128-channel instantiation exists and is tested, but inside the step it loses: 19.32 vs 18.82 ms - its four
-        # input-channel blocks re-stage the same 128-channel g tile and a third 128-CU grid queues behind the other two)
-        maxc = int(_knob('HRNET_FUSED_MAXC', '64'))     # (tests: restrict the fused path to narrow layers)
+        # Widths above 64 (the 128-channel instantiation): only where the LDS-ring pipeline does NOT serve the block's
+        # input-gradient convs. w32's 128-channel branch (16x16 maps) has the ring: fused loses there, 19.32 vs 18.82 ms -
+        # its four input-channel blocks re-stage the same 128-channel g tile. w48's 96-channel branch (48x36 maps) has
+        # only the tile-walking body: fused wins, 28.72 vs 29.92 ms/step (round 4).
+        maxc = int(_knob('HRNET_FUSED_MAXC', '128'))     # (tests: restrict the fused path to narrow layers)
+
+        def wide_ok(x, y1, y2):
+            if max(x.C, y1.C, y2.C) <= 64:
+                return True
+            return (C.call('hrnet_conv_route', self.dtid, x.N, x.H, x.W, y1.C, x.C, 3, 1) != 2
+                    and C.call('hrnet_conv_route', self.dtid, x.N, x.H, x.W, y2.C, y1.C, 3, 1) != 2)
         for ti in range(2, len(T)):
             e = T[ti]
             if e[0] != 'sum' or T[ti - 1][0] != 'conv' or T[ti - 2][0] != 'conv':
@@ -1321,7 +1329,7 @@ class Plan(object):
                   and idt.act is x and idt.bn is xin1.bn and idt.relu == xin1.relu and x.nuse == 2
                   and st1 == 1 and st2 == 1 and crec1.ks == 3 and crec2.ks == 3 and not crec1.stem
                   and crec1.mod.bias is None and crec2.mod.bias is None and x.g is not None
-                  and max(x.C, y1.C, y2.C) <= maxc
+                  and max(x.C, y1.C, y2.C) <= maxc and wide_ok(x, y1, y2)
                   and C.call('hrnet_bwd_fused_supported', self.dtid, x.C, y1.C)
                   and C.call('hrnet_bwd_fused_supported', self.dtid, y1.C, y2.C))
             # the mask the kernel applies to the gradient it stores for x is [a > 0], a = the conv's input as staged:
