@@ -488,6 +488,14 @@ def main():
             opt.step()
             return loss_dict['total_loss']
 
+    # (measurement, HRNET_MEASURE=1 HRNET_LANE0_PRIORITY=1: the step on a high-priority stream, i.e. lane 0 - the
+    # critical chain - above the side lanes)
+    prio_ctx = None
+    if os.environ.get('HRNET_MEASURE') == '1' and os.environ.get('HRNET_LANE0_PRIORITY', '0') != '0':
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        prio_ctx = torch.cuda.stream(hp)
+        prio_ctx.__enter__()
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
@@ -509,6 +517,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    if prio_ctx is not None:
+        prio_ctx.__exit__(None, None, None)
 
     roof = None
     extra_out = {}

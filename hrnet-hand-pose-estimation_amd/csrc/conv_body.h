@@ -725,8 +725,14 @@ TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool
   else if (Cout <= 32) tc = (Ho >= 16 && Wo >= 16) ? TileChoice{16, 16, 32, 0, 1, 0} : TileChoice{8, 8, 32, 3, 1, 0};
   // (not for backward-statistics launches: their epilogue operands do not fit 128 accumulators' registers)
   else if (ks == 1 && Cout >= 128 && Wo >= 16 && Ho >= 16 && !bs) tc = TileChoice{8, 16, 128, 4, 1, 0};  // GEMM-like
-  else if (Wo >= 16 && Ho >= 16) tc = TileChoice{8, 16, 64, 1, 1, 0};
-  else tc = TileChoice{8, 8, 64, 2, 1, 0};
+  else if (Wo >= 16 && Ho >= 16) {
+    tc = TileChoice{8, 16, 64, 1, 1, 0};
+    // maps whose width is far from a multiple of 16 (w48's 24x18 maps: 8x16 tiles cover 24x32 pixels, 8x8 tiles 24x24):
+    // the 8x8 tile when it walks at most HRNET_SMALL_TILE_PCT % of the pixels the 8x16 tile would
+    static const int pct = hr_knob("HRNET_SMALL_TILE_PCT", 80);
+    const long long p16 = (long long)((Ho + 7) / 8 * 8) * ((Wo + 15) / 16 * 16), p8 = (long long)((Ho + 7) / 8 * 8) * ((Wo + 7) / 8 * 8);
+    if (p8 * 100 <= p16 * pct) tc = TileChoice{8, 8, 64, 2, 1, 0};
+  } else tc = TileChoice{8, 8, 64, 2, 1, 0};
   const int tiles = N * ((Ho + tc.th - 1) / tc.th) * ((Wo + tc.tw - 1) / tc.tw);
   int gy = (Cout + tc.bn - 1) / tc.bn;
   // few workgroups on 8x8-tiled maps: halve BN for twice the workgroups (latency hiding beats reuse;
@@ -741,7 +747,7 @@ TileChoice choose_tile(int N, int Ho, int Wo, int Cout, int ks, int stride, bool
   // 2 resident workgroups per CU (register-limited) x 256 CUs: a grid of <= 512 workgroups runs as one
   // wave of workgroups with no tail; the rest of the tiles are walked by the same workgroups
   // (measured: 64->64 3x3 @64x64 40.1 us with 512 workgroups, 47.2 us with 683)
-  static const int wg_target = getenv("HRNET_CONV_WGS") ? atoi(getenv("HRNET_CONV_WGS")) : 512;   // (measurement override)
+  static const int wg_target = hr_knob("HRNET_CONV_WGS", 512);   // (measurement override)
   int tpw = (tiles2 * gy + wg_target - 1) / wg_target;
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;

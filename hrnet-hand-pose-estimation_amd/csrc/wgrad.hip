@@ -359,6 +359,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
         const int nci = min(KC, a.Cin_real - c0);      // real input channels of this block (<= 0: nothing to add)
+        // (round 4: starting every split at its own 64-float segment of the tile changes nothing, 25.3 us either way - the
+        // ~10 us the atomic form adds to a launch is the CU's own issue rate for float atomics, ~1 lane per cycle for the
+        // tile's 18 K floats whatever the split count, not a convoy on the addresses: scratch/wgrad_atomic_micro.py)
         for (int idx = tid; idx < HCO * KC * TAPS; idx += 256) {
           const int col = idx / (KC * TAPS), rem = idx - col * (KC * TAPS);
           const int co = co0 + h * HCO + col;
@@ -399,7 +402,13 @@ WgCfg choose_wg(int dtype, int Ho, int Wo, int Cout, int ks, int stride, int Cin
   // (measured 508 -> 365 us); narrower layers lose with it (64->256: 34 -> 48 us)
   if (ks == 1 && !f32 && Cout >= 256 && Cin >= 256) return WgCfg{8, 16, 128, 128, 11};
   if (ks == 1) return f32 ? WgCfg{8, 16, 64, 32, 10} : WgCfg{8, 16, 64, 64, 10};
-  const bool big = Ho >= 16 && Wo >= 16 && stride == 1;
+  bool big = Ho >= 16 && Wo >= 16 && stride == 1;
+  if (big) {
+    // (as choose_tile in conv_body.h: 8x8 tiles where they walk far fewer padded pixels than 16x16 ones - w48's 24x18 maps)
+    static const int pct = hr_knob("HRNET_SMALL_TILE_PCT", 80);
+    const long long p16 = (long long)((Ho + 15) / 16 * 16) * ((Wo + 15) / 16 * 16), p8 = (long long)((Ho + 7) / 8 * 8) * ((Wo + 7) / 8 * 8);
+    if (p8 * 100 <= p16 * pct) big = false;
+  }
   const int kc = f32 ? 16 : 32;
   if (Cout <= 32) return big ? WgCfg{16, 16, 32, kc, 0} : WgCfg{8, 8, 32, kc, 1};
   return big ? WgCfg{16, 16, 64, kc, 2} : WgCfg{8, 8, 64, kc, 3};
