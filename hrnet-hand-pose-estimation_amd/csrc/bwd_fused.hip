@@ -807,6 +807,8 @@ inline FusedCfg fused_cfg(int dtype, int Cout) {
   if (Cout <= 32) {
     if (var == 1) return FusedCfg{32, 16, 4, 1, 4, 0, 2};
     if (var == 2) return FusedCfg{32, 8, 4, 1, 4, 0, 2};   // (188 VGPRs: two 4-wave workgroups per CU)
+    // (round 4: 32x16 pixel tiles for this instantiation - half the barriers and staging waits per pixel - take 256 VGPRs
+    // + 112 bytes of scratch and 97 KB of LDS: 16.5 against 15.24 ms/step)
     return FusedCfg{32, 16, 8, 1, 8, 0, 1};
   }
   if (Cout <= 64) {
