@@ -11,9 +11,6 @@
 // (wave-uniform broadcast reads). NCHW f32 like the reference op.
 #include "common.h"
 
-#ifndef DCN_LDS_TAPS
-#define DCN_LDS_TAPS 9    // taps of dcn_bwd_fused_kernel whose scattered input gradient goes through LDS atomics (the others: global atomics)
-#endif
 #ifndef DCN_ABLATE
 #define DCN_ABLATE 0      // measurement builds (scratch/dcn_ablate.sh): 1 no LDS atomics, 2 one weight vector per tap, 4 no offset-gradient stores
 #endif
@@ -30,6 +27,7 @@ struct DcnArgs {
   float* gin;         // [B,C,H,W]   (atomic accumulation: zeroed by the caller)
   float* goff;        // [B,DG*2*K,Ho,Wo]
   float* partial;     // [blocks][Og][Cg][K]
+  const float* gmax;  // dcn_bwd_fused_kernel: [B] max |gout[b]| (the fixed-point scale of the input-gradient plane)
   // modulated form (DCNv2, reference src/cuda/modulated_deform_im2col_cuda.cuh:128-257): every sample is multiplied by
   // mask[b, dg*K + k, y, x]; NULL = plain v1
   const float* mask;  // [B,DG*K,Ho,Wo] or NULL
@@ -346,21 +344,31 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnArgs a) {
 // everything for the weight gradient). Per step of 256 pixels:
 //   phase 1 (thread = pixel): g[o] of the pixel, then per tap gc = sum_o W[o,c,k] * g[o], the four bilinear
 //           corners from the input plane staged in LDS, the offset gradient stored directly, the scattered
-//           input gradient added into an LDS plane (ds_add_f32); the sample and g go to LDS rows;
+//           input gradient added into an LDS plane; the sample and g go to LDS rows;
 //   phase 2 (thread = (o,k) pair): dW[o,c,k] += sum over the 256 pixels of g[o,p] * sample[k,p] (16-byte LDS
 //           reads), so the weight-gradient sums cost a thread one register instead of Og*K.
 // The planes are stored coalesced at the end; one partial [Og][C][K] per image, summed over the images in
 // fixed order by dcn_weight_reduce_kernel (deterministic).
+//
+// The input-gradient plane is a 64-bit FIXED-POINT plane (round 4). LDS float atomics (ds_add_f32) were 0.74 of this
+// kernel's 1.06 ms; integer LDS atomics run ~3.5x faster (scratch/lds_atom_t.hip: ds_add_u64 as fast as ds_add_u32).
+// Every contribution v (an f32 product) is added as round(v * 2^e): 2^e from a bound on the contributions of this
+// plane - max |gout[b]| (a[B] pre-pass, dcn_absmax_kernel) times the largest tap's sum of |W[o,c,k]| - chosen so that
+// one contribution stays below 2^50 and all plane_o * K of them in ONE cell below 2^62. An f32 value has 24 significant
+// bits, so what is added is the contribution itself unless it is more than 2^26 times smaller than the bound: the plane
+// holds the exact sum of the f32 contributions, rounded to f32 once when it is stored - closer to the f64 oracle than
+// float atomics, and the same bits on every run (integer addition commutes). The conversion is one f64 FMA: v * 2^e +
+// 1.5 * 2^52 leaves the rounded integer in the low mantissa bits.
 template <int OGP, int KK>
 __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LD = 260;           // padded row of 256 pixels (16-byte aligned, rows 4 banks apart)
   const int HW = a.H * a.W;
-  float* pl = sm;                   // [H*W] input plane
-  float* gpl = sm + HW;             // [H*W] input-gradient plane
-  float* wl = sm + 2 * HW;          // [KK][OGP] weights of this channel, zero beyond Og
-  float* gl = wl + KK * OGP;        // [OGP][LD] output gradients of the step's pixels
-  float* vl = gl + OGP * LD;        // [KK][LD] samples of the step's pixels
+  unsigned long long* gpl = reinterpret_cast<unsigned long long*>(sm);   // [H*W] input-gradient plane, 64-bit fixed point
+  float* pl = sm + 2 * HW;          // [H*W] input plane
+  float* wl = sm + 3 * HW;          // [KK][OGP] weights of this channel, zero beyond Og
+  float* gl = wl + KK * OGP;        // [Og][LD] output gradients of the step's pixels (Og rows: two workgroups per CU fit)
+  float* vl = gl + a.Og * LD;       // [KK][LD] samples of the step's pixels
   const int c = blockIdx.x, b = blockIdx.y;
   for (int i = threadIdx.x; i < KK * OGP; i += 256) {
     const int o = i % OGP, k = i / OGP;
@@ -369,11 +377,31 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   const float* in_p = a.in + ((size_t)b * a.C + c) * HW;
   for (int i = threadIdx.x; i < HW; i += 256) {
     pl[i] = in_p[i];
-    gpl[i] = 0.f;
+    gpl[i] = 0ull;
   }
   const int plane_o = a.Ho * a.Wo;
+  __syncthreads();          // wl is complete
+  // fixed-point scale 2^fe of this plane (wave-uniform arithmetic, every thread the same)
+  float wsum = 0.f;
+  for (int k = 0; k < KK; ++k) {
+    float t = 0.f;
+    for (int o = 0; o < OGP; ++o) t += fabsf(wl[k * OGP + o]);
+    wsum = fmaxf(wsum, t);
+  }
+  const float bound = a.gmax[b] * wsum;                 // >= |gc| of every (pixel, tap) of this plane
+  const bool finite = bound <= 3.0e38f;                 // (false for inf / NaN gradients: the plane is stored as NaN)
+  int bx = 0;
+  (void)frexpf(finite && bound > 0.f ? bound : 1.f, &bx);          // bound < 2^bx
+  int cells_log = 0;
+  while ((1ll << cells_log) < (long long)plane_o * KK) ++cells_log;
+  const int fe = (50 < 61 - cells_log ? 50 : 61 - cells_log) - bx;
+  const double fscale = ldexp(1.0, fe), funscale = ldexp(1.0, -fe);
+  constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
+  auto to_fixed = [&](float v) -> unsigned long long {
+    const double d = __builtin_fma((double)v, fscale, MAGIC);
+    return (unsigned long long)(__builtin_bit_cast(long long, d) - __builtin_bit_cast(long long, MAGIC));
+  };
   const size_t obase0 = ((size_t)b * a.DG + c) * 2 * KK * plane_o;
-  float* gout_plane = a.gin + ((size_t)b * a.C + c) * HW;       // (zeroed by the host when DCN_LDS_TAPS < 9)
   // phase 2 on the matrix pipe (round 4): dW[o][k] = sum_p g[o][p] * sample[k][p] is a (32 x 16) x K = 256 product per
   // step. v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate): lane (i = lane & 15, kk = lane >> 4) of a
   // 16-pixel chunk reads FOUR consecutive pixels 4 kk .. 4 kk + 3 of its row with one ds_read_b128 and feeds them to
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
         ow[k] = a.off[obase0 + (size_t)(2 * k + 1) * plane_o + p];
       }
 #pragma unroll
-      for (int o = 0; o < OGP; ++o) gl[o * LD + threadIdx.x] = g[o];
+      for (int o = 0; o < OGP; ++o)
+        if (o < a.Og) gl[o * LD + threadIdx.x] = g[o];
 #pragma unroll
       for (int k = 0; k < KK; ++k) {
         const int i = k / a.kw, j = k % a.kw;
@@ -429,14 +458,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
           gh = gc * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
           gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
 #if !(DCN_ABLATE & 1)
-          // the scattered input gradient: float atomics, taps < DCN_LDS_TAPS into the LDS plane (ds_add_f32: measured
-          // ~128 cycles per wave instruction = two cycles per lane, 0.74 of this kernel's 1.06 ms when all nine taps
-          // go there), the others straight into the global plane (global_atomic_add_f32, memory-side: another pipe)
-          float* gdst = k < DCN_LDS_TAPS ? gpl : gout_plane;
-          if (ok1) atomicAdd(gdst + hl * a.W + wl_, gc * hh * hw);
-          if (ok2) atomicAdd(gdst + hl * a.W + wh, gc * hh * lw);
-          if (ok3) atomicAdd(gdst + hh_ * a.W + wl_, gc * lh * hw);
-          if (ok4) atomicAdd(gdst + hh_ * a.W + wh, gc * lh * lw);
+          // the scattered input gradient: integer atomics into the fixed-point LDS plane
+          if (ok1) __hip_atomic_fetch_add(gpl + hl * a.W + wl_, to_fixed(gc * hh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok2) __hip_atomic_fetch_add(gpl + hl * a.W + wh, to_fixed(gc * hh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok3) __hip_atomic_fetch_add(gpl + hh_ * a.W + wl_, to_fixed(gc * lh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok4) __hip_atomic_fetch_add(gpl + hh_ * a.W + wh, to_fixed(gc * lh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
         }
 #if !(DCN_ABLATE & 4)
@@ -449,13 +475,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
       }
     } else {
 #pragma unroll
-      for (int o = 0; o < OGP; ++o) gl[o * LD + threadIdx.x] = 0.f;
+      for (int o = 0; o < OGP; ++o)
+        if (o < a.Og) gl[o * LD + threadIdx.x] = 0.f;
 #pragma unroll
       for (int k = 0; k < KK; ++k) vl[k * LD + threadIdx.x] = 0.f;
     }
     __syncthreads();
     {
-      const bool r0 = mi < OGP, r1 = 16 + mi < OGP, kc = mi < KK;
+      const bool r0 = mi < a.Og, r1 = 16 + mi < a.Og, kc = mi < KK;
       const float* g0p = gl + (r0 ? mi : 0) * LD + 4 * mk;
       const float* g1p = gl + (r1 ? 16 + mi : 0) * LD + 4 * mk;
       const float* vp = vl + (kc ? mi : 0) * LD + 4 * mk;
@@ -481,14 +508,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   }
   __syncthreads();
   float* out = a.gin + ((size_t)b * a.C + c) * HW;
-  if constexpr (DCN_LDS_TAPS >= KK) {
-    for (int i = threadIdx.x; i < HW; i += 256) out[i] = gpl[i];
-  } else {
-    for (int i = threadIdx.x; i < HW; i += 256) atomicAdd(out + i, gpl[i]);      // beside the taps added in place
-  }
+  for (int i = threadIdx.x; i < HW; i += 256)
+    out[i] = finite ? (float)((double)(long long)gpl[i] * funscale) : __builtin_nanf("");
   // the four waves' partial products meet in LDS (fixed order: deterministic); D layout: col (lane & 15) = tap,
   // row 4 * (lane >> 4) + r = output channel of the tile
-  float* red = gl;                   // [4 waves][32 o][16 taps] (the step buffers are free: 8 KB of gl's >= 24 KB)
+  float* red = gl;                   // [4 waves][32 o][16 taps] (the step buffers are free: 8 KB of gl + vl's >= 10 KB)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const float v4[4] = {accw[t].x, accw[t].y, accw[t].z, accw[t].w};
@@ -503,6 +527,22 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
                      red[(3 * 32 + po) * 16 + pk];
     a.partial[(size_t)b * a.Og * a.C * KK + ((size_t)po * a.C + c) * KK + pk] = dw;
   }
+}
+
+// out[b] = max |x[b, :]| (NaN / inf propagate as inf: the consumer then stores NaN planes)
+__global__ __launch_bounds__(256) void dcn_absmax_kernel(const float* x, float* out, long long n) {
+  __shared__ float red[4];
+  const float* p = x + (size_t)blockIdx.x * n;
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const float v = fabsf(p[i]);
+    m = (v > m || v != v) ? (v != v ? __builtin_inff() : v) : m;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // one wave per weight element: lanes stride over the per-block partials, fixed-shape tree at the end
@@ -664,12 +704,17 @@ static int dcn_backward_impl(const float* input, const float* offset, const floa
   const int cpd = C / deformable_groups;
   // single pass over the offsets for all three gradients (PoseAggr: 21 channels = 21 deformable groups, 3x3)
   const int ogp = Og <= 24 ? 24 : 32;
-  const size_t lds_one = ((size_t)2 * H * W + (size_t)9 * ogp + (size_t)(ogp + 9) * 260) * 4;
-  // (scratch holds hrnet_deform_conv_wgrad_blocks() partials of [Og][C][K]; this path writes B of them)
-  if (!mask && groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 80 * 1024 && B <= 65535 &&
-      hrnet_deform_conv_wgrad_blocks(B, Ho, Wo) >= B) {
+  // 64-bit gradient plane + f32 input plane + weights + Og + 9 rows of 260 floats (PoseAggr: 81 216 bytes - two workgroups per CU)
+  const size_t lds_one = ((size_t)3 * H * W + (size_t)9 * ogp + (size_t)(Og + 9) * 260) * 4;
+  // (scratch holds hrnet_deform_conv_wgrad_blocks() partials of [Og][C][K]; this path writes B of them, and the B
+  // per-image maxima of |grad_output| behind them)
+  if (!mask && groups == 1 && cpd == 1 && K == 9 && kh == 3 && Og <= 28 && lds_one <= 128 * 1024 && B <= 65535 &&
+      (size_t)(Og + 9) * 260 >= 4 * 32 * 16 &&
+      (size_t)hrnet_deform_conv_wgrad_blocks(B, Ho, Wo) * Og * Cg * K >= (size_t)B * Og * Cg * K + B) {
     a.c0 = 0; a.Cg = Cg; a.o0 = 0; a.Og = Og;
-    if (DCN_LDS_TAPS < 9) (void)hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), s);
+    float* gmax = scratch + (size_t)B * Og * Cg * K;
+    a.gmax = gmax;
+    hipLaunchKernelGGL(dcn_absmax_kernel, dim3(B), dim3(256), 0, s, grad_output, gmax, (long long)Co * Ho * Wo);
     if (ogp == 24) {
       want_lds(dcn_bwd_fused_kernel<24, 9>, lds_one);
       hipLaunchKernelGGL((dcn_bwd_fused_kernel<24, 9>), dim3(C, B), dim3(256), lds_one, s, a);

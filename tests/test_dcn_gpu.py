@@ -1,7 +1,7 @@
 """Deformable convolution on the HIP library vs the CPU oracle and the reference's own invariants
 (lib/deformable_conv/test.py). Tolerances: f32 arithmetic, sums of <= a few hundred products:
 1e-4 absolute on O(1..10) values; grad_input uses float atomics (order-dependent) like the
-reference's col2im."""
+reference's col2im - except on the PoseAggr geometry, whose single-pass backward sums it in fixed point."""
 import numpy as np
 import pytest
 import torch
@@ -192,6 +192,44 @@ def test_config5_backward_at_full_size():
     _, _, gw2, gb2 = grads(off[:2].contiguous(), go[:2].contiguous(), xs=x[:2].contiguous())
     assert np.abs(gw2.cpu().numpy() - gw_ref).max() <= 5e-5 * max(1.0, float(np.abs(gw_ref).max()))
     assert np.abs(gb2.cpu().numpy() - gb_ref).max() <= 5e-5 * max(1.0, float(np.abs(gb_ref).max()))
+
+
+def test_poseaggr_input_gradient_is_reproducible_and_scale_free():
+    """The single-pass backward of the PoseAggr geometry accumulates the scattered input gradient in a 64-bit fixed-point
+    LDS plane (csrc/dcn.hip, dcn_bwd_fused_kernel): (a) two launches on the same operands give the SAME BITS (integer
+    addition commutes; float atomics did not); (b) the plane's scale follows the operands - gradients scaled by 2^-60 and
+    by 2^+40 give the same result scaled by that power of two, bit for bit (a fixed scale would flush the first to zero
+    and overflow the second); (c) the result stays within the float64 oracle's tolerance (reference rule:
+    deform_im2col_cuda.cuh:192-247, col2im by atomicAdd); (d) an all-zero grad_output gives zeros, an inf gives NaN
+    planes for that image only."""
+    from deformable_conv import DeformConvFunction
+    rng = np.random.default_rng(11)
+    B, Cc, H, dil = 6, 21, 64, 3
+    x = torch.from_numpy(rng.standard_normal((B, Cc, H, H)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((Cc, Cc, 3, 3)) * 0.1).astype(np.float32)).to(DEV)
+    off = torch.from_numpy((rng.standard_normal((B, Cc * 18, H, H)) * 4).astype(np.float32)).to(DEV)
+    go = torch.from_numpy(rng.standard_normal((B, Cc, H, H)).astype(np.float32)).to(DEV)
+
+    def gin(g):
+        t = x.clone().requires_grad_(True)
+        out = DeformConvFunction.apply(t, off, w, None, 1, dil, dil, 1, Cc, 64)
+        out.backward(g)
+        return t.grad
+
+    a, b = gin(go), gin(go)
+    assert torch.equal(a, b)
+    for e in (-60, 40):
+        sc = float(2.0 ** e)
+        assert torch.equal(gin(go * sc), a * sc), e
+    gi, _, _, _ = D.deform_conv_backward(x[:1].cpu().numpy().astype(np.float64), off[:1].cpu().numpy().astype(np.float64),
+                                         w.cpu().numpy().astype(np.float64), go[:1].cpu().numpy().astype(np.float64),
+                                         (1, 1), (dil, dil), (dil, dil), 1, Cc)
+    assert np.abs(a[:1].cpu().numpy() - gi).max() <= 2e-5 * max(1.0, float(np.abs(gi).max()))
+    assert float(gin(torch.zeros_like(go)).abs().max()) == 0.0
+    bad = go.clone()
+    bad[2, 5, 7, 9] = float('inf')
+    gb = gin(bad)
+    assert bool(torch.isnan(gb[2]).all()) and torch.equal(gb[[0, 1, 3, 4, 5]], a[[0, 1, 3, 4, 5]])
 
 
 def test_bad_arguments_fail_loudly():
