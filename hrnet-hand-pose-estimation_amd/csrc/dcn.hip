@@ -52,8 +52,9 @@ __device__ __forceinline__ bool dcn_inside(float h, float w, int H, int W) {
   return h > -1.f && w > -1.f && h < (float)H && w < (float)W;
 }
 
-constexpr int OC = 32;  // output channels per thread pass
-
+// OC: output channels per thread pass (32; 24 when a conv group has at most 24 - PoseAggr's 21: a quarter fewer
+// multiply-adds and weight reads per sample)
+template <int OC>
 __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int oc0, int ocn) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cg*K][OC], zero beyond ocn
   const int K = a.kh * a.kw;
@@ -421,7 +422,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
       float g[OGP];
 #pragma unroll
       for (int o = 0; o < OGP; ++o) g[o] = o < a.Og ? a.gout[((size_t)b * a.Co + o) * plane_o + p] : 0.f;
-      float oh[KK], ow[KK];     // all offsets of this pixel first (18 independent loads in flight)
+      // all offsets of this pixel first (18 independent loads in flight). (Round 4: loading the NEXT step's offsets a
+      // step ahead - 18 more registers, 243 in all - made the launch slower, 571 against 540 us: the co-resident
+      // workgroup already fills the wait.)
+      float oh[KK], ow[KK];
 #pragma unroll
       for (int k = 0; k < KK; ++k) {
         oh[k] = a.off[obase0 + (size_t)(2 * k) * plane_o + p];
@@ -607,16 +611,22 @@ static int dcn_forward_impl(const float* input, const float* offset, const float
   HR_REQUIRE(input && offset && weight && output, "deform_conv_forward: null pointer");
   a.in = input; a.off = offset; a.w = weight; a.bias = bias; a.out = output; a.mask = mask;
   const int Cg = C / groups, Og = Co / groups, K = kh * kw;
+  const int OC = Og <= 24 ? 24 : 32;
   HR_REQUIRE((size_t)OC * Cg * K * 4 <= 96 * 1024, "deform_conv_forward: C/groups * kh * kw = %d too large", Cg * K);
   const long long npix = (long long)B * Ho * Wo;
   const unsigned blocks = (unsigned)((npix + 255) / 256);
-  want_lds(dcn_fwd_kernel, (size_t)OC * Cg * K * 4);
+  if (OC == 24) want_lds(dcn_fwd_kernel<24>, (size_t)OC * Cg * K * 4);
+  else want_lds(dcn_fwd_kernel<32>, (size_t)OC * Cg * K * 4);
   for (int g = 0; g < groups; ++g) {
     a.c0 = g * Cg; a.Cg = Cg;
     for (int o = 0; o < Og; o += OC) {
       const int ocn = Og - o < OC ? Og - o : OC;
-      hipLaunchKernelGGL(dcn_fwd_kernel, dim3(blocks), dim3(256), (size_t)OC * Cg * K * 4, (hipStream_t)stream, a,
-                         g * Og + o, ocn);
+      if (OC == 24)
+        hipLaunchKernelGGL(dcn_fwd_kernel<24>, dim3(blocks), dim3(256), (size_t)OC * Cg * K * 4, (hipStream_t)stream, a,
+                           g * Og + o, ocn);
+      else
+        hipLaunchKernelGGL(dcn_fwd_kernel<32>, dim3(blocks), dim3(256), (size_t)OC * Cg * K * 4, (hipStream_t)stream, a,
+                           g * Og + o, ocn);
     }
   }
   return hr_check_launch("deform_conv_forward");
