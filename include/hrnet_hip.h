@@ -567,7 +567,9 @@ int hrnet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * No column buffer is materialised, so the reference's im2col_step has no counterpart here (any
  * value gives the same result - the reference's own invariant, test.py:218-248).
  * backward: grad_input is accumulated with float atomics like the reference's col2im (zeroed
- * inside); grad_bias may be NULL; scratch holds hrnet_deform_conv_wgrad_blocks() *
+ * inside) - except on the PoseAggr geometry (one input channel per deformable group, groups = 1, 3x3,
+ * Co <= 28, planes that fit LDS), whose single-pass kernel sums it in a 64-bit fixed-point plane: the
+ * exact sum of the f32 contributions, the same bits on every run; grad_bias may be NULL; scratch holds hrnet_deform_conv_wgrad_blocks() *
  * (Co/groups)*(C/groups)*kh*kw floats. Limits: Co/groups <= 64 for backward, weight slice of one
  * group <= 96 KB.
  */
