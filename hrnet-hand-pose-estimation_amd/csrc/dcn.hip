@@ -117,6 +117,102 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs a, int oc0, int oc
     if (o < ocn) a.out[((size_t)b * a.Co + oc0 + o) * plane_o + (size_t)y * a.Wo + x] = acc[o];
 }
 
+// Forward with the input planes staged through LDS (round 4): a block owns NT consecutive output pixels of one image
+// and walks the conv group's channels; channel c's whole plane sits in LDS while its nine taps are sampled - the four
+// corner reads of a sample are LDS reads instead of L2 gathers - and channel c + 1's plane is loaded into registers
+// meanwhile (two LDS planes, one barrier per channel). Chosen when a plane fits (H*W <= 8 * NT floats, 2 planes + the
+// weights in 64 KB) and an image has at least NT output pixels: PoseAggr's 64x64 planes -> 4 blocks of 1024 threads per
+// image, 256 blocks. Same arithmetic as dcn_fwd_kernel in the same order: bit-identical output.
+template <int OC, int NT>
+__global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, int ocn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.kh * a.kw, HW = a.H * a.W;
+  float* wl = sm;                          // [Cg*K][OC], zero beyond ocn
+  float* pl = sm + OC * a.Cg * K;          // [2][H*W]
+  for (int i = threadIdx.x; i < OC * a.Cg * K; i += NT) {
+    const int o = i % OC, ck = i / OC;
+    wl[i] = o < ocn ? a.w[(size_t)(oc0 + o) * a.Cg * K + ck] : 0.f;
+  }
+  const int b = blockIdx.y;
+  const int plane_o = a.Ho * a.Wo;
+  const int p = blockIdx.x * NT + threadIdx.x;
+  const bool live = p < plane_o;
+  const int y = live ? p / a.Wo : 0, x = live ? p % a.Wo : 0;
+  constexpr int PV = 8;                    // plane floats per thread (host: H*W <= PV * NT)
+  float nx[PV];
+  const float* in_b = a.in + ((size_t)b * a.C + a.c0) * HW;
+#pragma unroll
+  for (int q = 0; q < PV; ++q) {
+    const int i = threadIdx.x + q * NT;
+    if (i < HW) pl[i] = in_b[i];
+  }
+  float acc[OC];
+#pragma unroll
+  for (int o = 0; o < OC; ++o) acc[o] = (a.bias && o < ocn) ? a.bias[oc0 + o] : 0.f;
+  const int cpd = a.C / a.DG;
+  __syncthreads();
+  for (int cl = 0; cl < a.Cg; ++cl) {
+    const float* plane = pl + (cl & 1) * HW;
+    if (cl + 1 < a.Cg) {
+#pragma unroll
+      for (int q = 0; q < PV; ++q) {
+        const int i = threadIdx.x + q * NT;
+        nx[q] = i < HW ? in_b[(size_t)(cl + 1) * HW + i] : 0.f;
+      }
+    }
+    if (live) {
+      const int c = a.c0 + cl;
+      const float* offp = a.off + ((size_t)b * a.DG + c / cpd) * 2 * K * plane_o + p;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        float hh[3], ww[3], vv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int k = k0 + u < K ? k0 + u : K - 1;
+          const int i = k / a.kw, j = k % a.kw;
+          hh[u] = (float)(y * a.sh - a.ph + i * a.dh) + offp[(size_t)(2 * k) * plane_o];
+          ww[u] = (float)(x * a.sw - a.pw + j * a.dw) + offp[(size_t)(2 * k + 1) * plane_o];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          vv[u] = (k0 + u < K && dcn_inside(hh[u], ww[u], a.H, a.W)) ? dcn_sample(plane, a.H, a.W, hh[u], ww[u]) : 0.f;
+        if (a.mask) {
+          const float* mp = a.mask + ((size_t)b * a.DG + c / cpd) * K * plane_o + p;
+#pragma unroll
+          for (int u = 0; u < 3; ++u) vv[u] *= mp[(size_t)(k0 + u < K ? k0 + u : K - 1) * plane_o];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int k = k0 + u < K ? k0 + u : K - 1;
+          const float val = vv[u];
+          const float4* wk = reinterpret_cast<const float4*>(wl + (cl * K + k) * OC);
+#pragma unroll
+          for (int o = 0; o < OC / 4; ++o) {
+            const float4 w4 = wk[o];
+            acc[4 * o] = fmaf(w4.x, val, acc[4 * o]);
+            acc[4 * o + 1] = fmaf(w4.y, val, acc[4 * o + 1]);
+            acc[4 * o + 2] = fmaf(w4.z, val, acc[4 * o + 2]);
+            acc[4 * o + 3] = fmaf(w4.w, val, acc[4 * o + 3]);
+          }
+        }
+      }
+    }
+    if (cl + 1 < a.Cg) {
+      float* nxt = pl + ((cl + 1) & 1) * HW;     // read by every thread in iteration cl - 1: the barrier below closed it
+#pragma unroll
+      for (int q = 0; q < PV; ++q) {
+        const int i = threadIdx.x + q * NT;
+        if (i < HW) nxt[i] = nx[q];
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+      if (o < ocn) a.out[((size_t)b * a.Co + oc0 + o) * plane_o + p] = acc[o];
+  }
+}
+
 // grad wrt input (atomics, as the reference's col2im) and wrt offsets (direct store: one thread owns
 // every (pixel, offset channel) of its deformable groups)
 template <int OCP>
@@ -381,7 +477,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
     gpl[i] = 0ull;
   }
   const int plane_o = a.Ho * a.Wo;
-  __syncthreads();          // wl is complete
+  __syncthreads();          // wl, pl and the zeroed gradient plane are complete
   // fixed-point scale 2^fe of this plane (wave-uniform arithmetic, every thread the same)
   float wsum = 0.f;
   for (int k = 0; k < KK; ++k) {
@@ -407,7 +503,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   // step. v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate): lane (i = lane & 15, kk = lane >> 4) of a
   // 16-pixel chunk reads FOUR consecutive pixels 4 kk .. 4 kk + 3 of its row with one ds_read_b128 and feeds them to
   // four MFMAs (the pairing of pixels with k indices is free as long as both operands use the same one). A wave takes
-  // every fourth chunk: 4 chunks x (2 + 1) 16-byte reads per step instead of 128 per (o, k) thread - the LDS pipe was
+  // the four chunks of its own 64 pixels: 4 chunks x (2 + 1) 16-byte reads per step instead of 128 per (o, k) thread - the LDS pipe was
   // active 87 % of the kernel's time before (SQ_LDS_IDX_ACTIVE 2.0 M cycles per CU of 2.3 M), phase 2 alone issued
   // ~3000 of its ~6300 LDS cycles per step. Rows beyond Og / taps beyond 9 are fed zeros.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -416,7 +512,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   for (int p0 = 0; p0 < plane_o; p0 += 256) {
     const int p = p0 + threadIdx.x;
     const bool live = p < plane_o;
-    __syncthreads();          // staging done (first step) / phase 2 of the previous step has read gl, vl
+    // (no workgroup barrier inside the walk: a wave's phase 2 reads only the 64 pixels its own lanes wrote - LDS
+    // operations of one wave complete in order - so the four waves drift apart and fill each other's waits)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (live) {
       const int y = p / a.Wo, x = p % a.Wo;
       float g[OGP];
@@ -484,7 +582,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
 #pragma unroll
       for (int k = 0; k < KK; ++k) vl[k * LD + threadIdx.x] = 0.f;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     {
       const bool r0 = mi < a.Og, r1 = 16 + mi < a.Og, kc = mi < KK;
       const float* g0p = gl + (r0 ? mi : 0) * LD + 4 * mk;
@@ -493,7 +591,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int ch = (wave + 4 * q) * 16;                  // this wave's q-th chunk of 16 pixels
+        const int ch = (wave * 4 + q) * 16;                  // q-th chunk of 16 of this wave's own 64 pixels
         const float4 a0 = r0 ? *reinterpret_cast<const float4*>(g0p + ch) : z4;
         const float4 a1 = r1 ? *reinterpret_cast<const float4*>(g1p + ch) : z4;
         const float4 bv = kc ? *reinterpret_cast<const float4*>(vp + ch) : z4;
@@ -617,6 +715,19 @@ static int dcn_forward_impl(const float* input, const float* offset, const float
   const unsigned blocks = (unsigned)((npix + 255) / 256);
   if (OC == 24) want_lds(dcn_fwd_kernel<24>, (size_t)OC * Cg * K * 4);
   else want_lds(dcn_fwd_kernel<32>, (size_t)OC * Cg * K * 4);
+  // planes through LDS (dcn_fwd_planes_kernel) where they fit and an image fills 1024-thread blocks
+  constexpr int PNT = 1024;
+  const size_t lds_planes = ((size_t)OC * Cg * K + (size_t)2 * H * W) * 4;
+  static const int planes_on = hr_knob("HRNET_DCN_FWD_PLANES", 1);   // (measurement: 0 = the gather kernel)
+  if (planes_on && OC == 24 && (long long)H * W <= 8 * PNT && lds_planes <= 64 * 1024 && Ho * Wo >= PNT && B <= 65535) {
+    want_lds(dcn_fwd_planes_kernel<24, PNT>, lds_planes);
+    for (int g = 0; g < groups; ++g) {
+      a.c0 = g * Cg; a.Cg = Cg;
+      hipLaunchKernelGGL((dcn_fwd_planes_kernel<24, PNT>), dim3((Ho * Wo + PNT - 1) / PNT, B), dim3(PNT), lds_planes,
+                         (hipStream_t)stream, a, g * Og, Og);
+    }
+    return hr_check_launch("deform_conv_forward");
+  }
   for (int g = 0; g < groups; ++g) {
     a.c0 = g * Cg; a.Cg = Cg;
     for (int o = 0; o < Og; o += OC) {

@@ -89,6 +89,10 @@ CASES = [
     (1, 2, 6, 20, 2, 5, 1, 2, 1, 2, 1),         # 5x5 kernel
     (1, 80, 6, 6, 8, 3, 1, 1, 1, 1, 1),         # 92 KB weight slice in LDS, global-atomics path
     (2, 6, 12, 12, 6, 3, 1, 2, 1, 1, 1),        # 3 channels per deformable group on the LDS path
+    # forward with the planes staged through LDS (dcn_fwd_planes_kernel: >= 1024 output pixels per image)
+    (2, 21, 64, 64, 21, 3, 1, 21, 1, 3, 3),     # PoseAggr at its full plane size
+    (1, 6, 40, 41, 10, 3, 2, 3, 1, 1, 1),       # 1640 pixels: a partly idle second block; conv groups x shared offsets
+    (1, 4, 80, 72, 8, 3, 1, 2, 2, 1, 1),        # stride 2: 5760-float planes, 1440 output pixels
 ]
 
 
@@ -102,9 +106,19 @@ def test_forward_and_backward_match_the_oracle(shape):
     assert np.abs(out - ref).max() < 2e-5 * scale
     gi, goff, gw, gb = D.deform_conv_backward(c64['input'], c64['offset'], c64['weight'], go.astype(np.float64),
                                               c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    # (the offset gradient is discontinuous where a sample position crosses a pixel centre: positions within f32 rounding
+    # of an integer are left out, as in test_config5_backward_at_full_size - none at the small sizes, a handful of the
+    # 3 M elements of the 64x64 case)
+    B, C, H, W, Co, k, groups, DG, stride, pad, dil = shape
+    Ho, Wo = D._out_size(H, W, k, k, c['stride'], c['padding'], c['dilation'])
+    h, w_ = D._sample_positions(c64['offset'], (B, Ho, Wo), k, k, c['stride'], c['padding'], c['dilation'], DG)
+    near = (np.abs(h - np.round(h)) < 2e-4) | (np.abs(w_ - np.round(w_)) < 2e-4)          # [B, DG, K, Ho, Wo]
+    keep = ~np.repeat(near[:, :, :, None], 2, axis=3).reshape(goff.shape)
+    assert keep.mean() > 0.99
     for name, want in (('input', gi), ('offset', goff), ('weight', gw), ('bias', gb)):
         s = max(1.0, float(np.abs(want).max()))
-        assert np.abs(g[name] - want).max() < 5e-5 * s, name
+        m = keep if name == 'offset' else 1.0
+        assert np.abs((g[name] - want) * m).max() < 5e-5 * s, name
 
 
 def test_large_offsets_fall_outside_and_read_zero():
