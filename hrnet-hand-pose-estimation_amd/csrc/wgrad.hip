@@ -455,7 +455,8 @@ extern "C" int hrnet_wgrad_splits(int dtype, int N, int Ho, int Wo, int Cout, in
   // 25 us launch at two tiles per workgroup, scratch/wgrad_atomic_micro.py), so twice the tiles per workgroup halve that
   // share - w48 29.92 -> 29.40 ms/step; w32's deferred launches (64 tiles x 8 blocks) stay where they are
   static const int bigt = hr_knob("HRNET_WGRAD_BIG_TILES", 1024);   // (measurement: 0 = off)
-  if (ks == 3 && bigt > 0 && (long long)tiles * gy * gz >= bigt) target /= 2;
+  // (bf16 only: the f32 launches - 16-channel input blocks, twice the blocks - lose with it, 55.4 against 53.4 ms/step)
+  if (ks == 3 && dtype != HR_F32 && bigt > 0 && (long long)tiles * gy * gz >= bigt) target /= 2;
   int ns = target / (gy * gz);
   if (ns < 1) ns = 1;
   if (ns > 512) ns = 512;

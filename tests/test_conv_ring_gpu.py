@@ -241,7 +241,14 @@ def test_ring_input_gradient_with_backward_statistics(case):
     got = hh.from_nhwc(y1, Cc)
     assert not torch.isnan(got).any() and (r1 is None or not torch.isnan(r1).any())
     assert hh.rel_err(got, ref_store) <= TOL
-    if H == 8:
+    # the two bodies sum the taps and input-channel chunks in the same order where the tile-walking body takes its wide
+    # tile: the same bits. On 8x8 tiles (the 8x8 maps, and maps far from a multiple of 16 - 20x24 here - since round 4:
+    # choose_tile in csrc/conv_body.h) its order differs: bf16 rounding of the same sums
+    t5 = (ctypes.c_int * 5)()
+    C.call('hrnet_conv_tile_walk', N, H, W, Cc, 3, 1, 0 if masked == 'plain' else 1, 0, t5)
+    small = t5[1] == 8
+    assert small == (H == 8 or (H, W) == (20, 24))
+    if small:
         assert hh.rel_err(y1.float().cpu(), y0.float().cpu()) <= 4e-3
     else:
         assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), 'ring and tile-walking bodies differ'
@@ -249,7 +256,7 @@ def test_ring_input_gradient_with_backward_statistics(case):
         return
     scale = dz.double().abs().sum((0, 2, 3)).max().item()
     assert float((r1[0] - ref_rows[0]).abs().max()) <= (2 * TOL + 1e-5) * scale
-    assert float((r1 - r0).abs().max() / r0.abs().max()) <= (1e-5 if H != 8 else 2e-3)
+    assert float((r1 - r0).abs().max() / r0.abs().max()) <= (2e-3 if small else 1e-5)
 
 
 def test_recorded_backward_statistics_launch_keeps_its_kernel_family():
