@@ -845,7 +845,9 @@ extern "C" int hrnet_bwd_fused_splits(int dtype, int N, int H, int W, int Cin, i
   // (64x64 maps: 2048 workgroup-tiles at batch 64) sits in the single-lane tail of the backward pass and takes
   // every CU (165 us on 128 CUs)
   static const int big = hr_knob("HRNET_FUSED_CUS_BIG", 256);
-  static const int cus128 = hr_knob("HRNET_FUSED_CUS_128", 128);   // (measurement)
+  // the 128-channel instantiation (w48's 96-channel branch: three input-channel blocks per walk): 96 workgroups =
+  // 32 walks of 18 tiles; 28.3 against 28.8 ms/step with 128 (36 walks), 29.2 with 80, 29.0 with 192 / 256
+  static const int cus128 = hr_knob("HRNET_FUSED_CUS_128", 96);
   // (measurement: separate grids for the 32- and 64-channel instantiations, which run side by side on two lanes)
   static const int cus32 = hr_knob("HRNET_FUSED_CUS32", cus);
   static const int cus64 = hr_knob("HRNET_FUSED_CUS64", cus);

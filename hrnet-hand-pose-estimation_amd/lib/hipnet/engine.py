@@ -911,11 +911,12 @@ class Plan(object):
                             and _knob('HRNET_DEFER_WGRAD', '1') != '0')
         self.defer_branch_wgrads = _knob('HRNET_DEFER_BRANCH', '1') != '0'   # (measurement: fuse layers only)
         # how much weight-gradient work the single-lane tail can hide: the tail is a stream over the stem / layer1
-        # maps, so its length goes with their pixel count; 3.2 MFLOP per tail pixel is what w32 at B=64 hides in full
-        # (773 GFLOP behind a 4 ms tail). w48 has 1.9x the work per tail pixel: half of it stays in the modules
-        # (deferring all of it: 43.8 ms/step, none: 37.0)
+        # maps, so its length goes with their pixel count; w32 at B=64 needs 3.2 MFLOP per tail pixel to defer everything
+        # (773 GFLOP behind a 4 ms tail). w48 has 1.9x the work per tail pixel: part of it stays in the modules
+        # (deferring all of it: 43.8 ms/step, none: 37.0 in round 2; round 4, with the 96-channel branch on the fused
+        # backward: 2.4 -> 29.1, 3.2 -> 28.8, 4.5 -> 28.4, 6 -> 28.4 ms/step; w32 unchanged)
         tail_pixels = self.N * (self.H // 4) * (self.W // 4)
-        self._defer_budget = float(_knob('HRNET_DEFER_MFLOP_PER_PIXEL', '3.2')) * 1e6 * tail_pixels
+        self._defer_budget = float(_knob('HRNET_DEFER_MFLOP_PER_PIXEL', '4.5')) * 1e6 * tail_pixels
         self._defer_flops = 0.0
         self.offload_wgrad = self.defer_wgrad and not dp and _knob('HRNET_OFFLOAD_WGRAD', '1') != '0'
         self._offload_rr = 0
