@@ -527,7 +527,12 @@ def main():
     if rank == 0 and not args.no_roofline:
         stats, kinds = instrumented_step(model, x, gt, criterion)
         peak = PEAK_TFLOPS[args.dtype]
-        dom = max(stats.items(), key=lambda kv: kv[1][1])
+        # the dominant kernel: the largest share of the step's kernel time; instantiations within 3 % of the top (the two
+        # fused-backward kernels take turns from box to box, 2.99 / 3.00 ms) are told apart by their algorithmic bytes per
+        # step - the launch that moves more is the one the HBM roof is about - so that the named kernel does not flip
+        # between runs
+        top_ms = max(v[1] for v in stats.values())
+        dom = max((kv for kv in stats.items() if kv[1][1] >= 0.97 * top_ms), key=lambda kv: kv[1][3])
         name, (n, ms, fl, by) = dom
         ach = fl / (ms * 1e-3) / 1e12
         ach_bw = by / (ms * 1e-3) / 1e9                      # GB/s of algorithmic bytes
@@ -540,7 +545,8 @@ def main():
                     'frac': round(ach / peak, 5)}
         # (the runner-up by time, when it is another instantiation of the same family: the two fused-backward kernels
         # take turns at the top from box to box)
-        second = sorted(stats.items(), key=lambda kv: -kv[1][1])[1] if len(stats) > 1 else None
+        others = [kv for kv in sorted(stats.items(), key=lambda kv: -kv[1][1]) if kv[0] != name]
+        second = others[0] if others else None
         if second is not None:
             n2, ms2, fl2, by2 = second[1]
             roof['runner_up'] = {'kernel': second[0], 'launches_per_step': n2, 'avg_launch_us': round(ms2 / n2 * 1e3, 2),
