@@ -290,6 +290,18 @@ MCASES = [
 ]
 
 
+def test_modulated_forward_with_planes_through_lds():
+    """the modulated forward at >= 1024 output pixels per image takes dcn_fwd_planes_kernel (the mask multiplies every
+    sample there too): 1640 pixels, conv groups 2, three channels per deformable group, against the float64 oracle"""
+    shape = (1, 6, 40, 41, 10, 3, 2, 2, 1, 1, 1)
+    c = _mcase(77, *shape)
+    out = _mrun(c)
+    c64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    ref = D.modulated_deform_conv_forward(c64['input'], c64['offset'], c64['mask'], c64['weight'], c64['bias'],
+                                          c['stride'], c['padding'], c['dilation'], c['groups'], c['DG'])
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize('shape', MCASES)
 def test_modulated_forward_and_backward_match_the_oracle(shape):
     c = _mcase(31 + sum(shape), *shape)
