@@ -494,8 +494,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
   const int fe = (50 < 61 - cells_log ? 50 : 61 - cells_log) - bx;
   const double fscale = ldexp(1.0, fe), funscale = ldexp(1.0, -fe);
   constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
-  auto to_fixed = [&](float v) -> unsigned long long {
-    const double d = __builtin_fma((double)v, fscale, MAGIC);
+  // a contribution gc * w as round(gs * w), gs = gc * 2^fe in f64 (one conversion of gc per tap; the product is rounded
+  // once, in f64: |gs * w| < 2^50)
+  auto to_fixed2 = [&](double gs, float w) -> unsigned long long {
+    const double d = __builtin_fma(gs, (double)w, MAGIC);
     return (unsigned long long)(__builtin_bit_cast(long long, d) - __builtin_bit_cast(long long, MAGIC));
   };
   const size_t obase0 = ((size_t)b * a.DG + c) * 2 * KK * plane_o;
@@ -561,10 +563,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(DcnArgs a) {
           gw = gc * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
 #if !(DCN_ABLATE & 1)
           // the scattered input gradient: integer atomics into the fixed-point LDS plane
-          if (ok1) __hip_atomic_fetch_add(gpl + hl * a.W + wl_, to_fixed(gc * hh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (ok2) __hip_atomic_fetch_add(gpl + hl * a.W + wh, to_fixed(gc * hh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (ok3) __hip_atomic_fetch_add(gpl + hh_ * a.W + wl_, to_fixed(gc * lh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (ok4) __hip_atomic_fetch_add(gpl + hh_ * a.W + wh, to_fixed(gc * lh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const double gs = (double)gc * fscale;
+          if (ok1) __hip_atomic_fetch_add(gpl + hl * a.W + wl_, to_fixed2(gs, hh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok2) __hip_atomic_fetch_add(gpl + hl * a.W + wh, to_fixed2(gs, hh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok3) __hip_atomic_fetch_add(gpl + hh_ * a.W + wl_, to_fixed2(gs, lh * hw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ok4) __hip_atomic_fetch_add(gpl + hh_ * a.W + wh, to_fixed2(gs, lh * lw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
         }
 #if !(DCN_ABLATE & 4)
