@@ -613,7 +613,10 @@ def main():
             # rel-L2 (a broken tile walk hits single images or single tiles, not the whole batch alike); arg-max within
             # two heat-map pixels for at least SELFCHECK_ARGMAX2 of the (image, joint) maps (random-init maps are flat:
             # see DESIGN section 5 for the measured values)
-            ok = (loss_rel <= 1e-2 and worst_img <= max(3.0 * rel, 0.05) and agree2 >= SELFCHECK_ARGMAX2
+            # (at random-init weights - fewer than 3 warm-up steps - the maps are flat and the arg-max is decided by
+            # rounding: 0.46 within two pixels at --warmup 0, 0.66 at 1, 0.77-0.80 at 5; the bar is 0.3 there)
+            amin = SELFCHECK_ARGMAX2 if args.warmup >= 3 else 0.3
+            ok = (loss_rel <= 1e-2 and worst_img <= max(3.0 * rel, 0.05) and agree2 >= amin
                   and bool(torch.isfinite(hm16).all().item()))
             extra_out['selfcheck'] = {'loss_{}'.format(args.dtype): round(l16, 5), 'loss_fp32_device': round(l32, 5),
                                       'loss_rel_diff': round(loss_rel, 6), 'heatmap_rel_l2': round(rel, 5),
