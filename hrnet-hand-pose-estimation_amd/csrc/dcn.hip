@@ -48,6 +48,16 @@ __device__ __forceinline__ float dcn_sample(const float* plane, int H, int W, fl
   return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
 }
 
+// the same sample out of a plane with a one-pixel border of zeros (row pitch W2 = W + 2), for a position inside
+// (-1, H) x (-1, W): no bounds tests, identical arithmetic
+__device__ __forceinline__ float dcn_sample_bordered(const float* plane, int W2, float h, float w) {
+  const float fh = floorf(h), fw = floorf(w);
+  const int idx = ((int)fh + 1) * W2 + (int)fw + 1;
+  const float lh = h - fh, lw = w - fw, hh = 1.f - lh, hw = 1.f - lw;
+  const float v1 = plane[idx], v2 = plane[idx + 1], v3 = plane[idx + W2], v4 = plane[idx + W2 + 1];
+  return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
 __device__ __forceinline__ bool dcn_inside(float h, float w, int H, int W) {
   return h > -1.f && w > -1.f && h < (float)H && w < (float)W;
 }
@@ -127,8 +137,12 @@ template <int OC, int NT>
 __global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, int ocn) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = a.kh * a.kw, HW = a.H * a.W;
+  // the planes carry a one-pixel border of zeros: the four corners of a sample inside (-1, H) x (-1, W) are then read
+  // without bounds tests (two ds_read2_b32 from one address), and a corner outside the image contributes its weight
+  // times +0 - the value the gather kernel's `ok ? v : 0` gives
+  const int W2 = a.W + 2, HW2 = (a.H + 2) * W2;
   float* wl = sm;                          // [Cg*K][OC], zero beyond ocn
-  float* pl = sm + OC * a.Cg * K;          // [2][H*W]
+  float* pl = sm + OC * a.Cg * K;          // [2][(H+2)*(W+2)]
   for (int i = threadIdx.x; i < OC * a.Cg * K; i += NT) {
     const int o = i % OC, ck = i / OC;
     wl[i] = o < ocn ? a.w[(size_t)(oc0 + o) * a.Cg * K + ck] : 0.f;
@@ -140,11 +154,16 @@ __global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, 
   const int y = live ? p / a.Wo : 0, x = live ? p % a.Wo : 0;
   constexpr int PV = 8;                    // plane floats per thread (host: H*W <= PV * NT)
   float nx[PV];
+  int dst[PV];                             // bordered position of this thread's q-th plane element
   const float* in_b = a.in + ((size_t)b * a.C + a.c0) * HW;
+  for (int i = threadIdx.x; i < 2 * HW2; i += NT) pl[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < PV; ++q) {
     const int i = threadIdx.x + q * NT;
-    if (i < HW) pl[i] = in_b[i];
+    const int r = i / a.W;
+    dst[q] = (r + 1) * W2 + (i - r * a.W) + 1;
+    if (i < HW) pl[dst[q]] = in_b[i];
   }
   float acc[OC];
 #pragma unroll
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, 
   const int cpd = a.C / a.DG;
   __syncthreads();
   for (int cl = 0; cl < a.Cg; ++cl) {
-    const float* plane = pl + (cl & 1) * HW;
+    const float* plane = pl + (cl & 1) * HW2;
     if (cl + 1 < a.Cg) {
 #pragma unroll
       for (int q = 0; q < PV; ++q) {
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, 
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u)
-          vv[u] = (k0 + u < K && dcn_inside(hh[u], ww[u], a.H, a.W)) ? dcn_sample(plane, a.H, a.W, hh[u], ww[u]) : 0.f;
+          vv[u] = (k0 + u < K && dcn_inside(hh[u], ww[u], a.H, a.W)) ? dcn_sample_bordered(plane, W2, hh[u], ww[u]) : 0.f;
         if (a.mask) {
           const float* mp = a.mask + ((size_t)b * a.DG + c / cpd) * K * plane_o + p;
 #pragma unroll
@@ -197,11 +216,11 @@ __global__ __launch_bounds__(NT) void dcn_fwd_planes_kernel(DcnArgs a, int oc0, 
       }
     }
     if (cl + 1 < a.Cg) {
-      float* nxt = pl + ((cl + 1) & 1) * HW;     // read by every thread in iteration cl - 1: the barrier below closed it
+      float* nxt = pl + ((cl + 1) & 1) * HW2;    // read by every thread in iteration cl - 1: the barrier below closed it
 #pragma unroll
       for (int q = 0; q < PV; ++q) {
         const int i = threadIdx.x + q * NT;
-        if (i < HW) nxt[i] = nx[q];
+        if (i < HW) nxt[dst[q]] = nx[q];
       }
     }
     __syncthreads();
@@ -736,7 +755,7 @@ static int dcn_forward_impl(const float* input, const float* offset, const float
   else want_lds(dcn_fwd_kernel<32>, (size_t)OC * Cg * K * 4);
   // planes through LDS (dcn_fwd_planes_kernel) where they fit and an image fills 1024-thread blocks
   constexpr int PNT = 1024;
-  const size_t lds_planes = ((size_t)OC * Cg * K + (size_t)2 * H * W) * 4;
+  const size_t lds_planes = ((size_t)OC * Cg * K + (size_t)2 * (H + 2) * (W + 2)) * 4;
   static const int planes_on = hr_knob("HRNET_DCN_FWD_PLANES", 1);   // (measurement: 0 = the gather kernel)
   if (planes_on && OC == 24 && (long long)H * W <= 8 * PNT && lds_planes <= 64 * 1024 && Ho * Wo >= PNT && B <= 65535) {
     want_lds(dcn_fwd_planes_kernel<24, PNT>, lds_planes);

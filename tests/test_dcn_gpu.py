@@ -121,6 +121,40 @@ def test_forward_and_backward_match_the_oracle(shape):
         assert np.abs((g[name] - want) * m).max() < 5e-5 * s, name
 
 
+_FWD_CHILD = '''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from deformable_conv import DeformConvFunction
+rng = np.random.default_rng(3)
+x = torch.from_numpy(rng.standard_normal((3, 21, 64, 64)).astype(np.float32)).cuda()
+w = torch.from_numpy((rng.standard_normal((21, 21, 3, 3)) * 0.1).astype(np.float32)).cuda()
+b = torch.from_numpy(rng.random(21).astype(np.float32)).cuda()
+off = torch.from_numpy((rng.standard_normal((3, 378, 64, 64)) * 7).astype(np.float32)).cuda()
+out = DeformConvFunction.apply(x, off, w, b, 1, 6, 6, 1, 21, 64)
+np.save(sys.argv[2], out.cpu().numpy())
+'''
+
+
+def test_forward_through_lds_planes_equals_the_gather_kernel_bit_for_bit(tmp_path):
+    """dcn_fwd_planes_kernel (planes staged in LDS with a border of zeros, corners read without bounds tests) against
+    dcn_fwd_kernel (four guarded L2 gathers per sample) on the PoseAggr geometry with offsets of several pixels - many
+    samples on and beyond the image border: the same arithmetic in the same order, so the same bits. The gather kernel
+    runs in a child process (its switch, HRNET_DCN_FWD_PLANES=0 with HRNET_MEASURE=1, is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'hrnet-hand-pose-estimation_amd', 'lib')
+    outs = []
+    for planes in ('1', '0'):
+        f = str(tmp_path / ('fwd_planes_%s.npy' % planes))
+        env = dict(os.environ, HRNET_MEASURE='1', HRNET_DCN_FWD_PLANES=planes)
+        r = subprocess.run([sys.executable, '-c', _FWD_CHILD, lib, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_large_offsets_fall_outside_and_read_zero():
     c = _case(5, 2, 4, 8, 8, 4, 3, 1, 1, 1, 1, 1, scale=20.0)
     out = _run(c)
